@@ -1,0 +1,37 @@
+# Build recipes.  `make` builds everything that can be built on a machine
+# without a GPU: the host library, the HIP library (cross-compiled for gfx950),
+# the command-line front end and the test oracle.
+ROCM     ?= /opt/rocm
+HIPCC    ?= $(ROCM)/bin/hipcc
+CXX      ?= g++
+CC       ?= gcc
+PKG      := pathtracing_amd
+HOSTSRC  := $(wildcard $(PKG)/csrc/host/*.cpp)
+DEVSRC   := $(wildcard $(PKG)/csrc/device/*.hip)
+DEVHDR   := $(wildcard $(PKG)/csrc/device/*.h) $(wildcard include/*.h)
+CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -Iinclude
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Iinclude -Wall
+
+all: host device cli oracle
+
+host: $(PKG)/libpthost.so
+device: $(PKG)/libptamd.so
+cli: $(PKG)/ptmain
+oracle: oracle/libptoracle.so
+
+$(PKG)/libpthost.so: $(HOSTSRC) $(PKG)/csrc/host/scene.hpp include/pathtracing_host.h include/pathtracing_amd.h
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOSTSRC)
+
+$(PKG)/libptamd.so: $(DEVSRC) $(DEVHDR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEVSRC)
+
+$(PKG)/ptmain: $(PKG)/csrc/cli/ptmain.cpp $(PKG)/libpthost.so $(PKG)/libptamd.so
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG) -lpthost -lptamd -Wl,-rpath,'$$ORIGIN' -L$(ROCM)/lib -Wl,-rpath,$(ROCM)/lib
+
+oracle/libptoracle.so: oracle/pt_oracle.c
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(PKG)/libpthost.so $(PKG)/libptamd.so $(PKG)/ptmain oracle/libptoracle.so
+
+.PHONY: all host device cli oracle clean

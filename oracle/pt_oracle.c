@@ -1,0 +1,915 @@
+/*
+ * pt_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, fp64, CPU restatement of the render hot path of the reference
+ * path tracer (gtangg12/Pathtracing).  It exists so that the GPU path can be
+ * checked against it; it is never the thing shipped or measured as the
+ * product.  Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of
+ * bench.py may load it.
+ *
+ * Parity pin: the reference cannot be compiled in this image (its util/*.cpp
+ * need OpenCV and Boost headers, which are absent), so this restatement is
+ * pinned by known answers instead: the kd-tree reference counts published in
+ * project.pdf Table 1 (cbox 12440/9073, car 97248/67293) and the values the
+ * survey recorded from the reference's code (tree shape, root boxes, sum of
+ * primary hit distances, ray census, mean linear RGB).  tests/test_oracle_pins.py
+ * holds them.
+ *
+ * Every function cites the reference lines it follows (paths relative to the
+ * reference checkout).  Arithmetic is written operation by operation in the
+ * reference's evaluation order; build with -ffp-contract=off and without
+ * -march flags that enable FMA.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Vec3 -- util/utilities.cpp:26-162                                   */
+/* ------------------------------------------------------------------ */
+typedef struct { double x, y, z; } V3;
+
+static inline V3 v3(double x, double y, double z) { V3 r = {x, y, z}; return r; }
+static inline V3 vadd(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }     /* :73 */
+static inline V3 vsub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }     /* :78 */
+static inline V3 vscale(double k, V3 a) { return v3(k * a.x, k * a.y, k * a.z); }     /* :83 */
+static inline V3 vmul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }     /* :88 */
+static inline V3 vdivs(V3 a, double k) { return v3(a.x / k, a.y / k, a.z / k); }      /* :93 */
+static inline double vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   /* :147 */
+static inline V3 vcross(V3 a, V3 b) {                                                 /* :152 */
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline double vlen(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }   /* :136 */
+static inline V3 vunit(V3 a) { double m = vlen(a); return v3(a.x / m, a.y / m, a.z / m); } /* :141 */
+static inline V3 vreflect(V3 u, V3 n) {                                               /* :160 */
+    return vsub(u, vscale(2 * vdot(u, n), n));
+}
+static inline double vget(V3 a, int i) { return i == 0 ? a.x : i == 1 ? a.y : a.z; }  /* :32 */
+
+/* ------------------------------------------------------------------ */
+/* Scene -- util/polygonMesh.cpp:25-46, util/lighting.cpp:9-15         */
+/* ------------------------------------------------------------------ */
+typedef struct { int vi[3], ni[3], ti[3]; int tm, reft; } Tri;
+typedef struct { int rows, cols; uint8_t *bgr; } Tex;
+typedef struct {
+    V3 albedo;
+    int nv, nn, nt, ntri, ntex;
+    V3 *vert, *norm;
+    double *uv;          /* 2 per entry */
+    Tri *tris;
+    V3 *cent;
+    Tex *tex;
+} Mesh;
+typedef struct { int type; double mag; V3 pos, color; } Light;
+
+typedef struct KD {
+    V3 lo, hi;
+    int axis;
+    double splt;
+    int leaf;
+    struct KD *left, *right;
+    int n;               /* number of (mesh,tri) entries held by this node */
+    int *m, *t;          /* mesh index, triangle index                     */
+} KD;
+
+typedef struct {
+    double eye[3], step, astep, angle, zoom;
+    V3 background;
+    int nlight; Light *light;
+    int nmesh; Mesh *mesh;
+    KD *root;
+    long tris, sum, sum2;          /* util/kdtree.cpp:63-65 */
+    long n_nodes, n_leaves, max_depth, max_leaf;
+} Scene;
+
+typedef struct { V3 src, dir, inv; int sign[3]; } Ray;
+
+/* util/polygonMesh.cpp:14-19 */
+static inline Ray mkray(V3 src, V3 dir) {
+    Ray r;
+    r.src = src; r.dir = dir;
+    r.inv = v3(1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z);
+    r.sign[0] = signbit(dir.x) ? 1 : 0;
+    r.sign[1] = signbit(dir.y) ? 1 : 0;
+    r.sign[2] = signbit(dir.z) ? 1 : 0;
+    return r;
+}
+
+/* ------------------------------------------------------------------ */
+/* Packed scene file ("PTSCENE1", little endian).                      */
+/*   magic[8]; f64 eye[3], step, astep, angle, zoom; f64 background[3] */
+/*   u32 nlight; {i32 type; f64 mag; f64 pos[3]; f64 color[3]} each    */
+/*   u32 nmesh; per mesh: f64 albedo[3]; u32 nv, nn, nt, ntri, ntex;   */
+/*     f64 vert[3*nv]; f64 norm[3*nn]; f64 uv[2*nt];                   */
+/*     i32 tri[11*ntri] (vi3, ni3, ti3, tm, reft);                     */
+/*     per texture: u32 rows, cols; u8 bgr[rows*cols*3]                */
+/* ------------------------------------------------------------------ */
+static int rd(FILE *f, void *p, size_t n) { return fread(p, 1, n, f) == n ? 0 : -1; }
+
+Scene *orc_scene_load(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    char magic[8];
+    Scene *s = (Scene *)calloc(1, sizeof(Scene));
+    double cam[7], bg[3];
+    uint32_t u;
+    if (rd(f, magic, 8) || memcmp(magic, "PTSCENE1", 8)) goto fail;
+    if (rd(f, cam, sizeof cam) || rd(f, bg, sizeof bg)) goto fail;
+    memcpy(s->eye, cam, 3 * sizeof(double));
+    s->step = cam[3]; s->astep = cam[4]; s->angle = cam[5]; s->zoom = cam[6];
+    s->background = v3(bg[0], bg[1], bg[2]);
+    if (rd(f, &u, 4)) goto fail;
+    s->nlight = (int)u;
+    s->light = (Light *)calloc(u ? u : 1, sizeof(Light));
+    for (int i = 0; i < s->nlight; i++) {
+        int32_t ty; double d[7];
+        if (rd(f, &ty, 4) || rd(f, d, sizeof d)) goto fail;
+        s->light[i].type = ty; s->light[i].mag = d[0];
+        s->light[i].pos = v3(d[1], d[2], d[3]);
+        s->light[i].color = v3(d[4], d[5], d[6]);
+    }
+    if (rd(f, &u, 4)) goto fail;
+    s->nmesh = (int)u;
+    s->mesh = (Mesh *)calloc(u ? u : 1, sizeof(Mesh));
+    for (int i = 0; i < s->nmesh; i++) {
+        Mesh *m = &s->mesh[i];
+        double alb[3]; uint32_t c[5];
+        if (rd(f, alb, sizeof alb) || rd(f, c, sizeof c)) goto fail;
+        m->albedo = v3(alb[0], alb[1], alb[2]);
+        m->nv = c[0]; m->nn = c[1]; m->nt = c[2]; m->ntri = c[3]; m->ntex = c[4];
+        m->vert = (V3 *)malloc(sizeof(V3) * (m->nv + 1));
+        m->norm = (V3 *)malloc(sizeof(V3) * (m->nn + 1));
+        m->uv = (double *)malloc(sizeof(double) * 2 * (m->nt + 1));
+        m->tris = (Tri *)malloc(sizeof(Tri) * (m->ntri + 1));
+        m->cent = (V3 *)malloc(sizeof(V3) * (m->ntri + 1));
+        m->tex = (Tex *)calloc(m->ntex + 1, sizeof(Tex));
+        if (rd(f, m->vert, sizeof(V3) * m->nv) || rd(f, m->norm, sizeof(V3) * m->nn) ||
+            rd(f, m->uv, sizeof(double) * 2 * m->nt) || rd(f, m->tris, sizeof(Tri) * m->ntri))
+            goto fail;
+        for (int k = 0; k < m->ntex; k++) {
+            uint32_t rc[2];
+            if (rd(f, rc, sizeof rc)) goto fail;
+            m->tex[k].rows = rc[0]; m->tex[k].cols = rc[1];
+            size_t nb = (size_t)rc[0] * rc[1] * 3;
+            m->tex[k].bgr = (uint8_t *)malloc(nb ? nb : 1);
+            if (rd(f, m->tex[k].bgr, nb)) goto fail;
+        }
+        /* centroid, util/reader.cpp:113 */
+        for (int k = 0; k < m->ntri; k++) {
+            Tri *t = &m->tris[k];
+            m->cent[k] = vdivs(vadd(vadd(m->vert[t->vi[0]], m->vert[t->vi[1]]), m->vert[t->vi[2]]), 3.0);
+        }
+    }
+    fclose(f);
+    return s;
+fail:
+    fclose(f);
+    free(s);
+    return NULL;
+}
+
+/* ------------------------------------------------------------------ */
+/* kd-tree build -- util/kdtree.cpp:54-59, 88-172, 262-281             */
+/* ------------------------------------------------------------------ */
+#define LEAF 3                              /* util/kdtree.cpp:14 */
+static const double TRAV = 5.0, INST = 5.0; /* util/kdtree.cpp:68-69 */
+
+static double surface_area(V3 lo, V3 hi) {  /* util/kdtree.cpp:54-59 */
+    double l = hi.x - lo.x, w = hi.y - lo.y, h = hi.z - lo.z;
+    return 2.0 * (l * w + w * h + l * h);
+}
+static void vset(V3 *a, int i, double v) { if (i == 0) a->x = v; else if (i == 1) a->y = v; else a->z = v; }
+static int cmp_double(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+static int cmp_pair(const void *a, const void *b) {
+    const int *p = (const int *)a, *q = (const int *)b;
+    if (p[0] != q[0]) return (p[0] > q[0]) - (p[0] < q[0]);
+    return (p[1] > q[1]) - (p[1] < q[1]);
+}
+static KD *kd_new(void) { return (KD *)calloc(1, sizeof(KD)); }
+
+static void kd_build(Scene *s, KD *nd, int depth) {
+    int n = nd->n;
+    s->n_nodes++;
+    if (depth > s->max_depth) s->max_depth = depth;
+    if (n <= LEAF) { s->sum += n; nd->leaf = 1; goto leafstats; }      /* :89-93 */
+    nd->axis = depth % 3;                                               /* :96 */
+    int ax = nd->axis;
+    double *pn = (double *)malloc(sizeof(double) * n);                  /* :98-101 */
+    for (int i = 0; i < n; i++) pn[i] = vget(s->mesh[nd->m[i]].cent[nd->t[i]], ax);
+    qsort(pn, n, sizeof(double), cmp_double);
+    V3 llo = nd->lo, lhi = nd->hi, rlo = nd->lo, rhi = nd->hi;          /* :103-104 */
+    double minv = DBL_MAX, sa = surface_area(nd->lo, nd->hi);           /* :106-108 */
+    for (int i = 0; i < n; i++) {                                       /* :109-120 */
+        double curr = pn[i];
+        vset(&lhi, ax, curr);
+        vset(&rlo, ax, curr);
+        double lsa = surface_area(llo, lhi), rsa = surface_area(rlo, rhi);
+        double cost = TRAV + lsa / sa * (i + 1) * INST + rsa / sa * (double)(size_t)(n - i - 1) * INST;
+        if (cost < minv) { minv = cost; nd->splt = curr; }
+    }
+    free(pn);
+    if (INST * n <= minv) { s->sum += n; nd->leaf = 1; goto leafstats; } /* :121-127 */
+    vset(&lhi, ax, nd->splt);                                           /* :128-129 */
+    vset(&rlo, ax, nd->splt);
+    KD *L = kd_new(), *R = kd_new();
+    L->lo = llo; L->hi = lhi; R->lo = rlo; R->hi = rhi;
+    L->m = (int *)malloc(sizeof(int) * n); L->t = (int *)malloc(sizeof(int) * n);
+    R->m = (int *)malloc(sizeof(int) * n); R->t = (int *)malloc(sizeof(int) * n);
+    for (int i = 0; i < n; i++) {                                       /* :131-141 */
+        Mesh *me = &s->mesh[nd->m[i]];
+        Tri *tr = &me->tris[nd->t[i]];
+        int l = 0, r = 0;
+        for (int j = 0; j < 3; j++) {
+            double c = vget(me->vert[tr->vi[j]], ax);
+            if (c <= nd->splt) l = 1;
+            if (c >= nd->splt) r = 1;
+        }
+        if (l) { L->m[L->n] = nd->m[i]; L->t[L->n] = nd->t[i]; L->n++; }
+        if (r) { R->m[R->n] = nd->m[i]; R->t[R->n] = nd->t[i]; R->n++; }
+    }
+    if ((L->n > R->n ? L->n : R->n) == n) {                             /* :143-149 */
+        s->sum += n; nd->leaf = 1;
+        free(L->m); free(L->t); free(R->m); free(R->t); free(L); free(R);
+        goto leafstats;
+    }
+    nd->left = L; nd->right = R;
+    kd_build(s, L, depth + 1);                                          /* :150-151 */
+    kd_build(s, R, depth + 1);
+    /* pull-up, :153-171: entries held by BOTH children move to this node;
+       left keeps its order, right is rewritten in sorted (mesh,tri) order. */
+    {
+        int nr = R->n, nl = L->n;
+        int *rs = (int *)malloc(sizeof(int) * 2 * (nr + 1));
+        for (int i = 0; i < nr; i++) { rs[2 * i] = R->m[i]; rs[2 * i + 1] = R->t[i]; }
+        qsort(rs, nr, 2 * sizeof(int), cmp_pair);
+        /* std::set semantics: duplicates collapse */
+        int nu = 0;
+        for (int i = 0; i < nr; i++)
+            if (nu == 0 || rs[2 * i] != rs[2 * (nu - 1)] || rs[2 * i + 1] != rs[2 * (nu - 1) + 1]) {
+                rs[2 * nu] = rs[2 * i]; rs[2 * nu + 1] = rs[2 * i + 1]; nu++;
+            }
+        char *gone = (char *)calloc(nu + 1, 1);
+        int *lm = L->m, *lt = L->t;
+        int *nm = (int *)malloc(sizeof(int) * (nl + 1)), *nt = (int *)malloc(sizeof(int) * (nl + 1));
+        int *pm = (int *)malloc(sizeof(int) * (nl + 1)), *pt = (int *)malloc(sizeof(int) * (nl + 1));
+        int np = 0, nnl = 0;
+        for (int i = 0; i < nl; i++) {
+            int key[2] = {lm[i], lt[i]};
+            int *hit = (int *)bsearch(key, rs, nu, 2 * sizeof(int), cmp_pair);
+            if (hit && !gone[(hit - rs) / 2]) {
+                gone[(hit - rs) / 2] = 1;
+                pm[np] = lm[i]; pt[np] = lt[i]; np++;
+            } else { nm[nnl] = lm[i]; nt[nnl] = lt[i]; nnl++; }
+        }
+        free(nd->m); free(nd->t);
+        nd->m = pm; nd->t = pt; nd->n = np;
+        free(L->m); free(L->t);
+        L->m = nm; L->t = nt; L->n = nnl;
+        int k = 0;
+        for (int i = 0; i < nu; i++)
+            if (!gone[i]) { R->m[k] = rs[2 * i]; R->t[k] = rs[2 * i + 1]; k++; }
+        R->n = k;
+        free(rs); free(gone);
+        s->sum2 += L->n + R->n;
+    }
+    return;
+leafstats:
+    s->n_leaves++;
+    if (n > s->max_leaf) s->max_leaf = n;
+}
+
+/* util/kdtree.cpp:262-281 */
+void orc_build_tree(Scene *s) {
+    KD *root = kd_new();
+    long total = 0;
+    for (int i = 0; i < s->nmesh; i++) total += s->mesh[i].ntri;
+    s->tris = total;
+    root->m = (int *)malloc(sizeof(int) * (total + 1));
+    root->t = (int *)malloc(sizeof(int) * (total + 1));
+    for (int i = 0; i < s->nmesh; i++)
+        for (int j = 0; j < s->mesh[i].ntri; j++) { root->m[root->n] = i; root->t[root->n] = j; root->n++; }
+    V3 mn = v3(0, 0, 0), mx = v3(0, 0, 0);
+    for (int i = 0; i < s->nmesh; i++)
+        for (int j = 0; j < s->mesh[i].nv; j++) {
+            V3 p = s->mesh[i].vert[j];
+            if (p.x < mn.x) mn.x = p.x; if (p.y < mn.y) mn.y = p.y; if (p.z < mn.z) mn.z = p.z;
+            if (p.x > mx.x) mx.x = p.x; if (p.y > mx.y) mx.y = p.y; if (p.z > mx.z) mx.z = p.z;
+        }
+    root->lo = vsub(mn, v3(0.01, 0.01, 0.01));
+    root->hi = vadd(mx, v3(0.01, 0.01, 0.01));
+    s->root = root;
+    s->sum = s->sum2 = 0;
+    s->n_nodes = s->n_leaves = s->max_depth = s->max_leaf = 0;
+    kd_build(s, root, 0);
+}
+
+/* ------------------------------------------------------------------ */
+/* Intersection + search -- util/polygonMesh.cpp:54-74,                */
+/* util/kdtree.cpp:30-49, 180-197, 216-257                             */
+/* ------------------------------------------------------------------ */
+typedef struct { long searches, node_visits, tri_tests, leaves; } Cnt;
+
+static inline int tri_intersect(const Mesh *me, int ind, const Ray *ray, double *t, double *bu, double *bv) {
+    const int *V = me->tris[ind].vi;
+    V3 ba = vsub(me->vert[V[1]], me->vert[V[0]]);
+    V3 ca = vsub(me->vert[V[2]], me->vert[V[0]]);
+    V3 P = vcross(ray->dir, ca);
+    double det = vdot(P, ba);
+    V3 T = vsub(ray->src, me->vert[V[0]]);
+    double u = vdot(P, T) / det;
+    if (u < 0.0 || u > 1.0) return 0;
+    V3 Q = vcross(T, ba);
+    double v = vdot(Q, ray->dir) / det;
+    if (v < 0.0 || u + v > 1.0) return 0;
+    *t = vdot(Q, ca) / det;
+    *bu = u; *bv = v;
+    return 1;
+}
+
+/* util/kdtree.cpp:30-49 */
+static inline int box_intersect(V3 lo, V3 hi, const Ray *r, double *ent, double *ext) {
+    double tmin, tmax, ymin, ymax, zmin, zmax;
+    tmin = ((r->sign[0] ? hi.x : lo.x) - r->src.x) * r->inv.x;
+    tmax = ((r->sign[0] ? lo.x : hi.x) - r->src.x) * r->inv.x;
+    ymin = ((r->sign[1] ? hi.y : lo.y) - r->src.y) * r->inv.y;
+    ymax = ((r->sign[1] ? lo.y : hi.y) - r->src.y) * r->inv.y;
+    if ((tmin > ymax) || (ymin > tmax)) return 0;
+    if (ymin > tmin) tmin = ymin;
+    if (ymax < tmax) tmax = ymax;
+    zmin = ((r->sign[2] ? hi.z : lo.z) - r->src.z) * r->inv.z;
+    zmax = ((r->sign[2] ? lo.z : hi.z) - r->src.z) * r->inv.z;
+    if ((tmin > zmax) || (zmin > tmax)) return 0;
+    *ent = tmin; *ext = tmax;
+    return 1;
+}
+
+typedef struct { int m, t; double tmin, u, v; } Hit;
+
+/* util/kdtree.cpp:180-197 */
+static inline int search_node(const Scene *s, const KD *nd, const Ray *ray, Hit *h, Cnt *c) {
+    int found = 0;
+    c->node_visits++;
+    for (int i = 0; i < nd->n; i++) {
+        double t, bu, bv;
+        c->tri_tests++;
+        if (tri_intersect(&s->mesh[nd->m[i]], nd->t[i], ray, &t, &bu, &bv) && t > 0 && t < h->tmin) {
+            V3 hit = vadd(ray->src, vscale(t, ray->dir));
+            if (!(hit.x >= nd->lo.x && hit.y >= nd->lo.y && hit.z >= nd->lo.z &&
+                  hit.x <= nd->hi.x && hit.y <= nd->hi.y && hit.z <= nd->hi.z))
+                continue;
+            found = 1;
+            h->tmin = t; h->u = bu; h->v = bv; h->m = nd->m[i]; h->t = nd->t[i];
+        }
+    }
+    return found;
+}
+
+#define STK 256
+/* util/kdtree.cpp:216-257.  h->tmin is in/out exactly as the reference's tmin. */
+static int search_ref(const Scene *s, const Ray *ray, Hit *h, Cnt *c) {
+    double ent, ext;
+    const KD *curr = s->root;
+    c->searches++;
+    if (!box_intersect(curr->lo, curr->hi, ray, &ent, &ext)) return 0;
+    const KD *sn[STK]; double se[STK], sx[STK];
+    int sp = 0;
+    sn[sp] = curr; se[sp] = ent; sx[sp] = ext; sp++;
+    int found = 0;
+    while (sp > 0) {
+        sp--;
+        curr = sn[sp]; ent = se[sp]; ext = sx[sp];
+        if (ent >= h->tmin) break;
+        while (!curr->leaf) {
+            found |= search_node(s, curr, ray, h, c);
+            double sp_ = curr->splt;
+            int a = curr->axis;
+            double da = vget(ray->dir, a);
+            double tdir = da == 0 ? 0.0000001 : da;
+            double tmid = (sp_ - vget(ray->src, a)) / tdir;
+            const KD *nr = curr->left, *fr = curr->right;
+            if (vget(ray->src, a) > sp_) { const KD *x = nr; nr = fr; fr = x; }
+            if (tmid >= ext || tmid < 0)
+                curr = nr;
+            else if (tmid <= ent && tmid <= h->tmin)
+                curr = fr;
+            else {
+                if (tmid <= h->tmin) {
+                    if (sp >= STK) { fprintf(stderr, "oracle: stack overflow\n"); abort(); }
+                    sn[sp] = fr; se[sp] = tmid; sx[sp] = ext; sp++;
+                }
+                curr = nr;
+                ext = tmid;
+            }
+        }
+        c->leaves++;
+        if (search_node(s, curr, ray, h, c)) return 1;
+    }
+    return found;
+}
+
+/* Nearest hit over every triangle, same intersect, same strict compares,
+   no in-box filter; mesh-major order.  Defines the non-degenerate mask. */
+static int search_brute(const Scene *s, const Ray *ray, Hit *h) {
+    int found = 0;
+    for (int m = 0; m < s->nmesh; m++)
+        for (int k = 0; k < s->mesh[m].ntri; k++) {
+            double t, bu, bv;
+            if (tri_intersect(&s->mesh[m], k, ray, &t, &bu, &bv) && t > 0 && t < h->tmin) {
+                found = 1; h->tmin = t; h->u = bu; h->v = bv; h->m = m; h->t = k;
+            }
+        }
+    return found;
+}
+
+/* ------------------------------------------------------------------ */
+/* Shading -- util/polygonMesh.cpp:81-118, util/lighting.cpp:24-59     */
+/* ------------------------------------------------------------------ */
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+/* cv::Mat::at<Vec3b>(Point(x,y)) reads row y, column x.  The reference does
+   not bounds-check; indices are clamped into the image here so that the
+   restatement never reads outside the texture. */
+static inline const uint8_t *texel(const Tex *tx, int px, int py) {
+    int row = clampi(py, 0, tx->rows - 1), col = clampi(px, 0, tx->cols - 1);
+    return tx->bgr + ((size_t)row * tx->cols + col) * 3;
+}
+
+static void surface_properties(const Mesh *me, int ind, double bu, double bv, V3 *nrm, V3 *txt, int *reft) {
+    const Tri *tr = &me->tris[ind];
+    const int *N = tr->ni;
+    double w = 1.0 - bu - bv;
+    *nrm = vunit(vadd(vadd(vscale(w, me->norm[N[0]]), vscale(bu, me->norm[N[1]])), vscale(bv, me->norm[N[2]])));
+    int mn = tr->tm;
+    *reft = tr->reft;
+    if (mn == -99999) { *txt = v3(1, 1, 1); return; }
+    const int *T = tr->ti;
+    if (mn < 0) {                                                       /* :96-103 */
+        mn = -(mn + 1);
+        const Tex *tx = &me->tex[mn];
+        int r = (int)((me->uv[2 * T[0]] * w + me->uv[2 * T[1]] * bu + me->uv[2 * T[2]] * bv) * tx->rows);
+        int c = (int)((me->uv[2 * T[0] + 1] * w + me->uv[2 * T[1] + 1] * bu + me->uv[2 * T[2] + 1] * bv) * tx->rows);
+        const uint8_t *p = texel(tx, r, c);
+        *txt = vdivs(v3(p[2], p[1], p[0]), 256.0);
+    } else {                                                            /* :104-117 */
+        const Tex *tx = &me->tex[mn];
+        V3 col[3];
+        for (int i = 0; i < 3; i++) {
+            int r = 0, c = 0;
+            if (T[i] != -1) {
+                r = (int)(me->uv[2 * T[i]] * tx->rows);
+                c = (int)(me->uv[2 * T[i] + 1] * tx->cols);
+            }
+            int px = r < 0 ? 0 : r; if (px > tx->rows) px = tx->rows;
+            int py = c < 0 ? 0 : c; if (py > tx->cols) py = tx->cols;
+            const uint8_t *p = texel(tx, px, py);
+            col[i] = v3(p[2], p[1], p[0]);
+        }
+        *txt = vdivs(vadd(vadd(vscale(w, col[0]), vscale(bu, col[1])), vscale(bv, col[2])), 256.0);
+    }
+}
+
+/* util/lighting.cpp:24-36 */
+static void illuminate(const Light *L, V3 hit, V3 *ldir, V3 *shade, double *dis) {
+    if (L->type == 'd') {
+        *dis = FLT_MAX;
+        *ldir = vunit(L->pos);
+        *shade = vscale(L->mag, L->color);
+    } else if (L->type == 'p') {
+        *ldir = vsub(L->pos, hit);
+        *dis = vlen(*ldir);
+        *ldir = vunit(*ldir);
+        *shade = vdivs(vscale(L->mag, L->color), 4 * *dis * M_PI);
+    }
+}
+
+/* util/lighting.cpp:42-48 */
+static void coord_system(V3 N, V3 *Nt, V3 *Nb) {
+    if (fabs(N.x) > fabs(N.y))
+        *Nt = vdivs(v3(N.z, 0, -N.x), sqrt(N.x * N.x + N.z * N.z));
+    else
+        *Nt = vdivs(v3(0, -N.z, N.y), sqrt(N.y * N.y + N.z * N.z));
+    *Nb = vcross(N, *Nt);
+}
+
+/* ------------------------------------------------------------------ */
+/* Random numbers.                                                     */
+/* RNG_LIBC  : rand()/RAND_MAX and libm sin/cos, util/lighting.cpp:53-59 */
+/* RNG_PHILOX: Philox4x32-10, key = (seed, view), counter = (pixel,    */
+/*             sample, 0, 0); r1, r2 are 53-bit uniforms in [0,1);     */
+/*             cos/sin(2*pi*r2) by the fixed-operation-order routine   */
+/*             below so that any IEEE-754 machine without contraction  */
+/*             produces the same bits.                                 */
+/* ------------------------------------------------------------------ */
+enum { RNG_LIBC = 0, RNG_PHILOX = 1 };
+
+static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+static inline double u53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+/* cos and sin of 2*pi*r, r in [0,1): exact octant reduction, then Taylor
+   polynomials on [0, pi/4] evaluated by Horner in x*x, multiply and add only. */
+static inline void sincos_2pi(double r, double *cs, double *sn) {
+    double q = r * 8.0;
+    int k = (int)q;
+    double f = q - (double)k;
+    if (k & 1) f = 1.0 - f;
+    double x = f * 0.78539816339744830962;
+    double z = x * x;
+    double s = 2.81145725434552076320e-15;          /*  1/17! */
+    s = s * z + -7.64716373181981647590e-13;        /* -1/15! */
+    s = s * z + 1.60590438368216145994e-10;         /*  1/13! */
+    s = s * z + -2.50521083854417187751e-08;        /* -1/11! */
+    s = s * z + 2.75573192239858906526e-06;         /*  1/9!  */
+    s = s * z + -1.98412698412698412698e-04;        /* -1/7!  */
+    s = s * z + 8.33333333333333333333e-03;         /*  1/5!  */
+    s = s * z + -1.66666666666666666667e-01;        /* -1/3!  */
+    s = s * z + 1.0;
+    s = s * x;
+    double c = 4.77947733238738529744e-14;          /*  1/16! */
+    c = c * z + -1.14707455977297247139e-11;        /* -1/14! */
+    c = c * z + 2.08767569878680989792e-09;         /*  1/12! */
+    c = c * z + -2.75573192239858906526e-07;        /* -1/10! */
+    c = c * z + 2.48015873015873015873e-05;         /*  1/8!  */
+    c = c * z + -1.38888888888888888889e-03;        /* -1/6!  */
+    c = c * z + 4.16666666666666666667e-02;         /*  1/4!  */
+    c = c * z + -0.5;
+    c = c * z + 1.0;
+    switch (k & 7) {
+        case 0: *cs = c;  *sn = s;  break;
+        case 1: *cs = s;  *sn = c;  break;
+        case 2: *cs = -s; *sn = c;  break;
+        case 3: *cs = -c; *sn = s;  break;
+        case 4: *cs = -c; *sn = -s; break;
+        case 5: *cs = -s; *sn = -c; break;
+        case 6: *cs = s;  *sn = -c; break;
+        default: *cs = c; *sn = -s; break;
+    }
+}
+void orc_sincos_2pi(double r, double *cs, double *sn) { sincos_2pi(r, cs, sn); }
+
+typedef struct {
+    int rng;                 /* RNG_LIBC / RNG_PHILOX */
+    uint32_t seed, view;
+    uint32_t pixel;          /* set per pixel */
+} Rng;
+
+/* util/lighting.cpp:53-59 */
+static V3 sample_hemisphere(const Rng *g, uint32_t sample, double *r1, double *r2) {
+    double cs, sn;
+    if (g->rng == RNG_LIBC) {
+        *r1 = ((double)rand()) / RAND_MAX;
+        *r2 = ((double)rand()) / RAND_MAX;
+        double phi = 2 * M_PI * *r2;
+        cs = cos(phi); sn = sin(phi);
+    } else {
+        uint32_t c[4] = {g->pixel, sample, 0u, 0u};
+        philox4x32_10(c, g->seed, g->view);
+        *r1 = u53(c[0], c[1]);
+        *r2 = u53(c[2], c[3]);
+        sincos_2pi(*r2, &cs, &sn);
+    }
+    double sinTheta = sqrt(1 - *r1 * *r1);
+    return v3(sinTheta * cs, *r1, sinTheta * sn);
+}
+
+/* ------------------------------------------------------------------ */
+/* castRay / globalIllumination / render                               */
+/*   MODEL_MAIN: main.cpp:41-147      MODEL_OMP: mainOMP.cpp:37-136     */
+/* ------------------------------------------------------------------ */
+enum { MODEL_MAIN = 0, MODEL_OMP = 1 };
+enum { C_PRIMARY = 0, C_SHADOW = 1, C_MIRROR = 2, C_GI = 3, C_DUMMY = 4, C_NCLASS = 5 };
+
+typedef struct { V3 clr, nrm, hit; } GBuf;
+typedef struct {
+    const Scene *s;
+    int model;
+    Cnt cnt[C_NCLASS];
+    long dummy_true;         /* times the OMP visibility re-trace reported a hit */
+    /* primary-hit record of the last depth-0 call */
+    int p_found, p_m, p_t; double p_tmin, p_u, p_v;
+} Ctx;
+
+/* depth: 0 primary, 1 mirror bounce (MAIN), -1 GI sample or OMP mirror. */
+static V3 cast_ray(Ctx *cx, const Ray *ray, int depth, int cls, GBuf *g) {
+    const Scene *s = cx->s;
+    Hit h; h.tmin = FLT_MAX; h.m = h.t = -1; h.u = h.v = 0;
+    int ok = search_ref(s, ray, &h, &cx->cnt[cls]);
+    if (depth == 0) { cx->p_found = ok; cx->p_m = h.m; cx->p_t = h.t; cx->p_tmin = h.tmin; cx->p_u = h.u; cx->p_v = h.v; }
+    if (!ok) {
+        if (depth == 0) { if (g) g->hit = v3(-99999, -99999, -99999); return s->background; }
+        return v3(0, 0, 0);
+    }
+    V3 nrm, txt; int reft;
+    surface_properties(&s->mesh[h.m], h.t, h.u, h.v, &nrm, &txt, &reft);
+    V3 hit = vadd(vadd(ray->src, vscale(h.tmin, ray->dir)), vscale(0.0001, nrm));
+    V3 direct = v3(0, 0, 0), ref = v3(0, 0, 0);
+    for (int k = 0; k < s->nlight; k++) {
+        V3 ldir = v3(0, 0, 0), shade = v3(0, 0, 0); double dis = 0;
+        illuminate(&s->light[k], hit, &ldir, &shade, &dis);
+        int vis;
+        if (cx->model == MODEL_MAIN) {                                   /* main.cpp:62-63 */
+            Ray lray = mkray(hit, ldir);
+            Hit sh; sh.tmin = dis; sh.m = sh.t = -1; sh.u = sh.v = 0;
+            vis = !search_ref(s, &lray, &sh, &cx->cnt[C_SHADOW]);
+        } else {                                                         /* mainOMP.cpp:59-60 */
+            Ray lray = mkray(hit, ldir); (void)lray;
+            int again = search_ref(s, ray, &h, &cx->cnt[C_DUMMY]);
+            if (again) cx->dummy_true++;
+            vis = !again;
+        }
+        double cosv = vdot(ldir, nrm);
+        double mx = (0.0 < cosv) ? cosv : 0.0;                           /* std::max(0.0, x) */
+        direct = vadd(direct, vscale((double)vis * mx, shade));
+    }
+    V3 alb = s->mesh[h.m].albedo;
+    if (depth == 0) {
+        if (g) { g->clr = vmul(txt, alb); g->hit = hit; g->nrm = nrm; }
+        if (reft) {
+            Ray rray = mkray(hit, vreflect(ray->dir, nrm));
+            if (cx->model == MODEL_MAIN)
+                ref = vadd(ref, cast_ray(cx, &rray, 1, C_MIRROR, NULL));     /* main.cpp:72-75 */
+            else
+                ref = vadd(ref, cast_ray(cx, &rray, -1, C_MIRROR, NULL));    /* mainOMP.cpp:69-72 */
+        }
+    }
+    V3 base = vdivs(vmul(vmul(txt, alb), direct), M_PI);                 /* (txt*albedo*direct)/pi */
+    if (cx->model == MODEL_OMP && depth == -1) return base;              /* mainOMP.cpp:74-75 */
+    /* 0.6*txt*albedo*direct/M_PI + 0.4*ref  (main.cpp:77, mainOMP.cpp:76) */
+    V3 a = vdivs(vmul(vmul(vscale(0.6, txt), alb), direct), M_PI);
+    return vadd(a, vscale(0.4, ref));
+}
+
+/* main.cpp:85-101, mainOMP.cpp:85-101 */
+static V3 global_illum(Ctx *cx, const Rng *g, int N, V3 nrm, V3 hit) {
+    V3 ind = v3(0, 0, 0), Nt, Nb;
+    if (hit.x == -99999 || N == 0) return ind;
+    coord_system(nrm, &Nt, &Nb);
+    for (int i = 0; i < N; i++) {
+        double r1, r2;
+        V3 sm = sample_hemisphere(g, (uint32_t)i, &r1, &r2);
+        V3 world = v3(sm.x * Nb.x + sm.y * nrm.x + sm.z * Nt.x,
+                      sm.x * Nb.y + sm.y * nrm.y + sm.z * Nt.y,
+                      sm.x * Nb.z + sm.y * nrm.z + sm.z * Nt.z);
+        Ray iray = mkray(hit, world);
+        ind = vadd(ind, vscale(r1, cast_ray(cx, &iray, -1, C_GI, NULL)));
+    }
+    return ind;
+}
+
+/* main.cpp:119-121, mainOMP.cpp:121-123 */
+static Ray camera_ray(V3 src, double zoom, double sa, double ca, int rows, int i, int j, double x, double y) {
+    V3 pxl = v3(0.5 - (double)(j + x) / rows, 0.5 - (double)(i + y) / rows, zoom);
+    V3 snk = v3(src.x + sa * pxl.x + ca * pxl.z, src.y + pxl.y, src.z - ca * pxl.x + sa * pxl.z);
+    return mkray(src, vunit(vsub(snk, src)));
+}
+
+typedef struct {
+    int model;        /* MODEL_MAIN / MODEL_OMP */
+    int gi, rb;
+    int spp;          /* 0 -> reference default (4 MAIN, 16 OMP) */
+    int rng;          /* RNG_LIBC / RNG_PHILOX */
+    uint32_t seed, view;
+    int size;         /* image rows = cols (reference: 512) */
+    int row0, row_step, nrows_limit; /* render rows row0, row0+row_step, ... (<= nrows_limit rows, 0 = all) */
+    int threads;      /* OpenMP threads (forced to 1 for RNG_LIBC) */
+} OrcOpts;
+
+typedef struct {
+    double *rgb;      /* size*size*3 linear RGB, may be NULL */
+    uint8_t *bgr;     /* size*size*3, may be NULL */
+    int32_t *mesh, *tri; double *t, *u, *v;   /* primary (centre or last) ray record, may be NULL */
+    int32_t *bmesh, *btri; double *bt;        /* brute-force nearest hit of the same ray, may be NULL */
+    double *gclr, *gnrm, *ghit;               /* G-buffers, 3 per pixel, may be NULL */
+    long counts[C_NCLASS * 4];                /* per class: searches, node_visits, tri_tests, leaves */
+    long dummy_true;
+    double seconds;
+} OrcOut;
+
+static double now_s(void) {
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return (double)clock() / CLOCKS_PER_SEC;
+#endif
+}
+
+/* The per-pixel work of both front ends.  MAIN (main.cpp:109-147) runs all
+   primaries first and the GI pass afterwards; with a counter RNG the result
+   per pixel does not depend on that order, and with RNG_LIBC the two passes
+   are kept separate below so that the rand() stream is consumed in the
+   reference's order. */
+static void pixel_primary(Ctx *cx, const OrcOpts *o, V3 src, double zoom, double sa, double ca,
+                          int i, int j, V3 *paint, GBuf *gb, int *rec_found, Hit *rec, Ray *rec_ray) {
+    double off = o->model == MODEL_MAIN ? 0.01 : 0.1;                    /* main.cpp:116 / mainOMP.cpp:117 */
+    V3 acc = v3(0, 0, 0);
+    double x, y;
+    for (y = -off; y <= off; y += off)
+        for (x = -off; x <= off; x += off) {
+            if (!o->rb && (x != 0 || y != 0)) continue;
+            Ray ray = camera_ray(src, zoom, sa, ca, o->size, i, j, x, y);
+            int centre = (x == 0 && y == 0);
+            /* MAIN: every sub-ray writes the pixel's G-buffer (last wins, main.cpp:68-70);
+               OMP: only the centre ray does (mainOMP.cpp:124-127). */
+            GBuf *g = (o->model == MODEL_MAIN || centre) ? gb : NULL;
+            GBuf scratch;
+            if (!g) g = &scratch;
+            acc = vadd(acc, cast_ray(cx, &ray, 0, C_PRIMARY, g));
+            if (o->model == MODEL_MAIN || centre) {
+                *rec_found = cx->p_found;
+                rec->m = cx->p_m; rec->t = cx->p_t; rec->tmin = cx->p_tmin; rec->u = cx->p_u; rec->v = cx->p_v;
+                *rec_ray = ray;
+            }
+        }
+    if (o->rb) acc = vdivs(acc, 9.0);
+    *paint = acc;
+}
+
+int orc_render(const Scene *s, const double eye[3], double angle, double zoom, const OrcOpts *o, OrcOut *out) {
+    int n = o->size;
+    int N = o->spp > 0 ? o->spp : (o->model == MODEL_MAIN ? 4 : 16);     /* main.cpp:129, mainOMP.cpp:132 */
+    V3 src = v3(eye[0], eye[1], eye[2]);
+    double sa = sin(angle), ca = cos(angle);
+    int threads = o->rng == RNG_LIBC ? 1 : (o->threads > 0 ? o->threads : 1);
+    int row_step = o->row_step > 0 ? o->row_step : 1;
+    int nrows = 0;
+    for (int i = o->row0; i < n; i += row_step) nrows++;
+    if (o->nrows_limit > 0 && nrows > o->nrows_limit) nrows = o->nrows_limit;
+    GBuf *gbuf = (GBuf *)calloc((size_t)n * n, sizeof(GBuf));
+    V3 *mpnt = (V3 *)calloc((size_t)n * n, sizeof(V3));
+    Cnt total[C_NCLASS]; memset(total, 0, sizeof total);
+    long dummy_true = 0;
+    if (o->rng == RNG_LIBC) srand(1);
+    double t0 = now_s();
+    int two_pass = (o->model == MODEL_MAIN);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        Ctx cx; memset(&cx, 0, sizeof cx); cx.s = s; cx.model = o->model;
+        Rng g; g.rng = o->rng; g.seed = o->seed; g.view = o->view; g.pixel = 0;
+#ifdef _OPENMP
+#pragma omp for schedule(static, 1)
+#endif
+        for (int ri = 0; ri < nrows; ri++) {
+            int i = o->row0 + ri * row_step;
+            for (int j = 0; j < n; j++) {
+                size_t p = (size_t)i * n + j;
+                V3 paint; int found = 0; Hit rec; Ray rray;
+                memset(&rec, 0, sizeof rec); rec.m = rec.t = -1;
+                pixel_primary(&cx, o, src, zoom, sa, ca, i, j, &paint, &gbuf[p], &found, &rec, &rray);
+                if (out->mesh) { out->mesh[p] = found ? rec.m : -1; out->tri[p] = found ? rec.t : -1; }
+                if (out->t) { out->t[p] = found ? rec.tmin : -1.0; out->u[p] = rec.u; out->v[p] = rec.v; }
+                if (out->bmesh) {
+                    Hit b; b.tmin = FLT_MAX; b.m = b.t = -1; b.u = b.v = 0;
+                    int bf = search_brute(s, &rray, &b);
+                    out->bmesh[p] = bf ? b.m : -1; out->btri[p] = bf ? b.t : -1;
+                    if (out->bt) out->bt[p] = bf ? b.tmin : -1.0;
+                }
+                if (!two_pass && o->gi) {                                /* mainOMP.cpp:129-134 */
+                    g.pixel = (uint32_t)p;
+                    V3 G = global_illum(&cx, &g, N, gbuf[p].nrm, gbuf[p].hit);
+                    paint = vadd(paint, vdivs(vmul(vscale(2.0, gbuf[p].clr), G), (double)N));
+                }
+                mpnt[p] = paint;
+            }
+        }
+        if (two_pass && o->gi) {                                         /* main.cpp:129-134 */
+#ifdef _OPENMP
+#pragma omp for schedule(static, 1)
+#endif
+            for (int ri = 0; ri < nrows; ri++) {
+                int i = o->row0 + ri * row_step;
+                for (int j = 0; j < n; j++) {
+                    size_t p = (size_t)i * n + j;
+                    g.pixel = (uint32_t)p;
+                    V3 G = global_illum(&cx, &g, N, gbuf[p].nrm, gbuf[p].hit);
+                    mpnt[p] = vadd(mpnt[p], vdivs(vmul(vscale(2.0, gbuf[p].clr), G), (double)N));
+                }
+            }
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            for (int c = 0; c < C_NCLASS; c++) {
+                total[c].searches += cx.cnt[c].searches; total[c].node_visits += cx.cnt[c].node_visits;
+                total[c].tri_tests += cx.cnt[c].tri_tests; total[c].leaves += cx.cnt[c].leaves;
+            }
+            dummy_true += cx.dummy_true;
+        }
+    }
+    out->seconds = now_s() - t0;
+    for (int c = 0; c < C_NCLASS; c++) {
+        out->counts[4 * c] = total[c].searches; out->counts[4 * c + 1] = total[c].node_visits;
+        out->counts[4 * c + 2] = total[c].tri_tests; out->counts[4 * c + 3] = total[c].leaves;
+    }
+    out->dummy_true = dummy_true;
+    for (int ri = 0; ri < nrows; ri++) {
+        int i = o->row0 + ri * row_step;
+        for (int j = 0; j < n; j++) {
+            size_t p = (size_t)i * n + j;
+            V3 c = mpnt[p];
+            if (out->rgb) { out->rgb[3 * p] = c.x; out->rgb[3 * p + 1] = c.y; out->rgb[3 * p + 2] = c.z; }
+            if (out->bgr) {                                              /* main.cpp:142-144 */
+                int b = (int)(255.0 * c.z), g_ = (int)(255.0 * c.y), r = (int)(255.0 * c.x);
+                out->bgr[3 * p] = (uint8_t)(b < 255 ? b : 255);
+                out->bgr[3 * p + 1] = (uint8_t)(g_ < 255 ? g_ : 255);
+                out->bgr[3 * p + 2] = (uint8_t)(r < 255 ? r : 255);
+            }
+            if (out->gclr) {
+                out->gclr[3 * p] = gbuf[p].clr.x; out->gclr[3 * p + 1] = gbuf[p].clr.y; out->gclr[3 * p + 2] = gbuf[p].clr.z;
+                out->gnrm[3 * p] = gbuf[p].nrm.x; out->gnrm[3 * p + 1] = gbuf[p].nrm.y; out->gnrm[3 * p + 2] = gbuf[p].nrm.z;
+                out->ghit[3 * p] = gbuf[p].hit.x; out->ghit[3 * p + 1] = gbuf[p].hit.y; out->ghit[3 * p + 2] = gbuf[p].hit.z;
+            }
+        }
+    }
+    free(gbuf); free(mpnt);
+    return 0;
+}
+
+/* Raw search for parity tests: n rays (src, dir, tmin_in) -> found, mesh, tri, t, u, v.
+   mode 0 = reference search (util/kdtree.cpp:216-257), 1 = brute force. */
+void orc_trace(const Scene *s, long n, const double *src, const double *dir, const double *tmin_in, int mode,
+               int32_t *found, int32_t *mesh, int32_t *tri, double *t, double *u, double *v) {
+    Cnt c; memset(&c, 0, sizeof c);
+    for (long i = 0; i < n; i++) {
+        Ray r = mkray(v3(src[3 * i], src[3 * i + 1], src[3 * i + 2]), v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+        Hit h; h.tmin = tmin_in[i]; h.m = h.t = -1; h.u = h.v = 0;
+        int ok = mode == 0 ? search_ref(s, &r, &h, &c) : search_brute(s, &r, &h);
+        found[i] = ok; mesh[i] = h.m; tri[i] = h.t; t[i] = h.tmin; u[i] = h.u; v[i] = h.v;
+    }
+}
+
+/* Camera rays of one view (centre rays), for tests of ray generation. */
+void orc_camera_rays(const double eye[3], double angle, double zoom, int size, double x, double y, double *dir) {
+    V3 src = v3(eye[0], eye[1], eye[2]);
+    double sa = sin(angle), ca = cos(angle);
+    for (int i = 0; i < size; i++)
+        for (int j = 0; j < size; j++) {
+            Ray r = camera_ray(src, zoom, sa, ca, size, i, j, x, y);
+            size_t p = (size_t)i * size + j;
+            dir[3 * p] = r.dir.x; dir[3 * p + 1] = r.dir.y; dir[3 * p + 2] = r.dir.z;
+        }
+}
+
+/* Hemisphere samples of the counter RNG, for tests: out = (x, y=r1, z) per sample. */
+void orc_hemisphere_samples(uint32_t seed, uint32_t view, uint32_t pixel, int n, double *out) {
+    Rng g; g.rng = RNG_PHILOX; g.seed = seed; g.view = view; g.pixel = pixel;
+    for (int i = 0; i < n; i++) {
+        double r1, r2;
+        V3 s = sample_hemisphere(&g, (uint32_t)i, &r1, &r2);
+        out[3 * i] = s.x; out[3 * i + 1] = s.y; out[3 * i + 2] = s.z;
+    }
+}
+
+/* Accessors used by the tests. */
+void orc_scene_camera(const Scene *s, double *out7) {
+    out7[0] = s->eye[0]; out7[1] = s->eye[1]; out7[2] = s->eye[2];
+    out7[3] = s->step; out7[4] = s->astep; out7[5] = s->angle; out7[6] = s->zoom;
+}
+void orc_tree_stats(const Scene *s, long *out8) {
+    out8[0] = s->tris; out8[1] = s->sum; out8[2] = s->sum2; out8[3] = s->n_nodes;
+    out8[4] = s->n_leaves; out8[5] = s->max_depth; out8[6] = s->max_leaf; out8[7] = s->root ? s->root->n : -1;
+}
+void orc_root_box(const Scene *s, double *out6) {
+    out6[0] = s->root->lo.x; out6[1] = s->root->lo.y; out6[2] = s->root->lo.z;
+    out6[3] = s->root->hi.x; out6[4] = s->root->hi.y; out6[5] = s->root->hi.z;
+}
+
+/* Pre-order dump of the tree for comparison with the host library's build:
+   per node 4 ints (leaf, axis, n_entries, first_entry_offset) and 7 doubles
+   (lo, hi, split); entries as (mesh, tri) pairs in node order. */
+static void dump_rec(const KD *nd, int32_t *ni, double *nd_, int32_t *ent, long *in, long *ie) {
+    long k = (*in)++;
+    if (ni) {
+        ni[4 * k] = nd->leaf; ni[4 * k + 1] = nd->leaf ? -1 : nd->axis; ni[4 * k + 2] = nd->n; ni[4 * k + 3] = (int32_t)*ie;
+        nd_[7 * k] = nd->lo.x; nd_[7 * k + 1] = nd->lo.y; nd_[7 * k + 2] = nd->lo.z;
+        nd_[7 * k + 3] = nd->hi.x; nd_[7 * k + 4] = nd->hi.y; nd_[7 * k + 5] = nd->hi.z;
+        nd_[7 * k + 6] = nd->leaf ? 0.0 : nd->splt;
+        for (int i = 0; i < nd->n; i++) { ent[2 * (*ie + i)] = nd->m[i]; ent[2 * (*ie + i) + 1] = nd->t[i]; }
+    }
+    *ie += nd->n;
+    if (!nd->leaf) { dump_rec(nd->left, ni, nd_, ent, in, ie); dump_rec(nd->right, ni, nd_, ent, in, ie); }
+}
+void orc_tree_dump(const Scene *s, int32_t *node_i, double *node_d, int32_t *entries, long *n_nodes, long *n_entries) {
+    long in = 0, ie = 0;
+    dump_rec(s->root, node_i, node_d, entries, &in, &ie);
+    *n_nodes = in; *n_entries = ie;
+}
