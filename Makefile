@@ -7,10 +7,15 @@ CXX      ?= g++
 CC       ?= gcc
 PKG      := pathtracing_amd
 HOSTSRC  := $(wildcard $(PKG)/csrc/host/*.cpp)
-DEVSRC   := $(wildcard $(PKG)/csrc/device/*.hip)
+DEVDIR   := $(PKG)/csrc/device
+DEVOBJ   := $(DEVDIR)/pt_abi.o $(DEVDIR)/pt_exact.o $(DEVDIR)/pt_fast.o
 DEVHDR   := $(wildcard $(PKG)/csrc/device/*.h) $(wildcard include/*.h)
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -Iinclude
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Iinclude -Wall
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Wall
+# The fp64 reference-semantics kernels must round after every operation; the
+# fp32 GI kernels may fuse multiply-adds.
+$(DEVDIR)/pt_abi.o $(DEVDIR)/pt_exact.o: CONTRACT := -ffp-contract=off
+$(DEVDIR)/pt_fast.o: CONTRACT := -ffp-contract=fast
 
 all: host device cli oracle
 
@@ -22,8 +27,11 @@ oracle: oracle/libptoracle.so
 $(PKG)/libpthost.so: $(HOSTSRC) $(PKG)/csrc/host/scene.hpp include/pathtracing_host.h include/pathtracing_amd.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOSTSRC)
 
-$(PKG)/libptamd.so: $(DEVSRC) $(DEVHDR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEVSRC)
+$(DEVDIR)/%.o: $(DEVDIR)/%.hip $(DEVHDR)
+	$(HIPCC) $(HIPFLAGS) $(CONTRACT) -c -o $@ $<
+
+$(PKG)/libptamd.so: $(DEVOBJ)
+	$(HIPCC) --offload-arch=gfx950 -shared -o $@ $(DEVOBJ)
 
 $(PKG)/ptmain: $(PKG)/csrc/cli/ptmain.cpp $(PKG)/libpthost.so $(PKG)/libptamd.so
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG) -lpthost -lptamd -Wl,-rpath,'$$ORIGIN' -L$(ROCM)/lib -Wl,-rpath,$(ROCM)/lib
@@ -32,6 +40,6 @@ oracle/libptoracle.so: oracle/pt_oracle.c
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(PKG)/libpthost.so $(PKG)/libptamd.so $(PKG)/ptmain oracle/libptoracle.so
+	rm -f $(DEVOBJ) $(PKG)/libpthost.so $(PKG)/libptamd.so $(PKG)/ptmain oracle/libptoracle.so
 
 .PHONY: all host device cli oracle clean

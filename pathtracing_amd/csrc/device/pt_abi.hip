@@ -1,0 +1,640 @@
+// C ABI of libptamd.so (include/pathtracing_amd.h): scene upload, view
+// rendering and raw ray queries on one MI355X.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pathtracing_amd.h"
+#include "pt_frame.h"
+
+#define PT_STACK_MAX 64   // per-lane stack of the fp64 search (pt_exact.h)
+
+namespace {
+
+thread_local std::string g_error;
+int g_device = -1;
+
+int fail(int code, const std::string &msg) { g_error = msg; return code; }
+
+float bits_to_float(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP,                      \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+struct Workspace {
+    int size = 0, batch = 0;
+    FrameBuffers F{};
+    FastBuffers Q{};
+    std::vector<void *> owned;
+};
+
+}  // namespace
+
+struct PtScene {
+    DevScene S{};
+    std::vector<void *> owned;        // device allocations of the scene
+    Workspace ws;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int max_depth = 0;
+    uint32_t n_tri = 0, n_mesh = 0;
+    std::vector<int32_t> tri_mesh, tri_local;   // host copies for (mesh, tri) reporting
+};
+
+namespace {
+
+template <typename T>
+int dev_copy(PtScene *sc, const T *src, size_t n, const T **out) {
+    void *d = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    HIPCHK(hipMalloc(&d, bytes));
+    sc->owned.push_back(d);
+    if (n) HIPCHK(hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T *)d;
+    return PT_OK;
+}
+
+template <typename T>
+int ws_alloc(Workspace &ws, size_t n, T **out) {
+    void *d = nullptr;
+    HIPCHK(hipMalloc(&d, (n ? n : 1) * sizeof(T)));
+    ws.owned.push_back(d);
+    *out = (T *)d;
+    return PT_OK;
+}
+
+int ws_alloc_cb(void *ctx, size_t bytes, void **out) {
+    Workspace &ws = *(Workspace *)ctx;
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    ws.owned.push_back(*out);
+    return PT_OK;
+}
+
+void ws_release(Workspace &ws) {
+    for (void *p : ws.owned) (void)hipFree(p);
+    ws = Workspace();
+}
+
+int validate_desc(const PtSceneDesc *d) {
+    if (!d) return fail(PT_ERR_INVALID, "scene description is null");
+    if (d->struct_size != sizeof(PtSceneDesc)) return fail(PT_ERR_INVALID, "PtSceneDesc.struct_size mismatch");
+    if (d->n_node == 0 || !d->nodes) return fail(PT_ERR_INVALID, "scene has no kd-tree (n_node == 0)");
+    if (d->n_tri && (!d->tri_vi || !d->tri_ni || !d->tri_ti || !d->tri_tm || !d->tri_reft || !d->tri_mesh || !d->tri_local))
+        return fail(PT_ERR_INVALID, "triangle arrays missing");
+    if ((d->n_vert && !d->vert) || (d->n_norm && !d->norm) || (d->n_uv && !d->uv) || (d->n_mesh && !d->mesh_albedo) ||
+        (d->n_tex && !d->tex) || (d->n_light && !d->lights) || (d->n_ref && !d->refs))
+        return fail(PT_ERR_INVALID, "a pool pointer is null while its count is not zero");
+    for (uint32_t t = 0; t < d->n_tri; t++) {
+        for (int k = 0; k < 3; k++) {
+            int32_t v = d->tri_vi[3 * t + k], n = d->tri_ni[3 * t + k], u = d->tri_ti[3 * t + k];
+            if (v < 0 || (uint32_t)v >= d->n_vert || n < 0 || (uint32_t)n >= d->n_norm || u < -1 ||
+                (u >= 0 && (uint32_t)u >= d->n_uv))
+                return fail(PT_ERR_INVALID, "triangle " + std::to_string(t) + ": index out of range");
+        }
+        int32_t tm = d->tri_tm[t];
+        if (tm != -99999) {
+            int32_t k = tm >= 0 ? tm : -(tm + 1);
+            if ((uint32_t)k >= d->n_tex) return fail(PT_ERR_INVALID, "triangle " + std::to_string(t) + ": texture index out of range");
+            if (tm < 0)
+                for (int c = 0; c < 3; c++)
+                    if (d->tri_ti[3 * t + c] < 0)
+                        return fail(PT_ERR_INVALID, "triangle " + std::to_string(t) + ": per-hit texture without uv");
+        }
+        if (d->tri_mesh[t] < 0 || (uint32_t)d->tri_mesh[t] >= d->n_mesh)
+            return fail(PT_ERR_INVALID, "triangle " + std::to_string(t) + ": mesh index out of range");
+    }
+    for (uint32_t r = 0; r < d->n_ref; r++)
+        if (d->refs[r] < 0 || (uint32_t)d->refs[r] >= d->n_tri) return fail(PT_ERR_INVALID, "kd reference out of range");
+    for (uint32_t k = 0; k < d->n_tex; k++)
+        if (d->tex[k].rows <= 0 || d->tex[k].cols <= 0 || !d->tex[k].bgr) return fail(PT_ERR_INVALID, "empty texture");
+    return PT_OK;
+}
+
+// Depth of the tree below node 0 and structural sanity (children in range, every
+// node reachable once, slices inside the ref array).
+int tree_depth(const PtSceneDesc *d, int *depth_out) {
+    std::vector<std::pair<int32_t, int>> todo;
+    std::vector<char> seen(d->n_node, 0);
+    todo.push_back({0, 0});
+    int maxd = 0;
+    while (!todo.empty()) {
+        auto [k, dep] = todo.back();
+        todo.pop_back();
+        if (k < 0 || (uint32_t)k >= d->n_node || seen[k]) return fail(PT_ERR_INVALID, "kd-tree links are not a tree");
+        seen[k] = 1;
+        const PtKdNode &n = d->nodes[k];
+        if (n.count < 0 || n.first < 0 || (uint64_t)n.first + (uint64_t)n.count > d->n_ref)
+            return fail(PT_ERR_INVALID, "kd node slice outside the reference array");
+        if (dep > maxd) maxd = dep;
+        if (n.axis >= 0) {
+            if (n.axis > 2) return fail(PT_ERR_INVALID, "kd node axis out of range");
+            todo.push_back({n.left, dep + 1});
+            todo.push_back({n.left + 1, dep + 1});
+        }
+    }
+    *depth_out = maxd;
+    return PT_OK;
+}
+
+int upload(const PtSceneDesc *d, PtScene **out) {
+    if (g_device < 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not been called");
+    if (!out) return fail(PT_ERR_INVALID, "out pointer is null");
+    int rc = validate_desc(d);
+    if (rc) return rc;
+    int depth = 0;
+    rc = tree_depth(d, &depth);
+    if (rc) return rc;
+    if (depth + 1 > PT_STACK_MAX)
+        return fail(PT_ERR_LIMIT, "kd-tree depth " + std::to_string(depth) + " exceeds the traversal stack (" +
+                                      std::to_string(PT_STACK_MAX) + ")");
+    PtScene *sc = new (std::nothrow) PtScene();
+    if (!sc) return fail(PT_ERR_OOM, "out of host memory");
+    auto bail = [&](int code) { pt_scene_free(sc); return code; };
+    sc->max_depth = depth;
+    sc->n_tri = d->n_tri; sc->n_mesh = d->n_mesh;
+    sc->tri_mesh.assign(d->tri_mesh, d->tri_mesh + d->n_tri);
+    sc->tri_local.assign(d->tri_local, d->tri_local + d->n_tri);
+    DevScene &S = sc->S;
+
+    // ---- tree: fp64 traversal nodes + boxes, fp32 nodes ----
+    std::vector<NodeA> na(d->n_node);
+    std::vector<double> nbox((size_t)d->n_node * 6);
+    std::vector<NodeF> nf(d->n_node);
+    for (uint32_t k = 0; k < d->n_node; k++) {
+        const PtKdNode &n = d->nodes[k];
+        na[k].split = n.split; na[k].axis = n.axis; na[k].left = n.left; na[k].first = n.first; na[k].count = n.count;
+        for (int c = 0; c < 3; c++) { nbox[6 * (size_t)k + c] = n.lo[c]; nbox[6 * (size_t)k + 3 + c] = n.hi[c]; }
+        nf[k].split = (float)n.split;
+        nf[k].link = n.axis < 0 ? 0xFFFFFFFFu : ((uint32_t)n.left | ((uint32_t)n.axis << 30));
+        nf[k].first = (uint32_t)n.first;
+        nf[k].count = (uint32_t)n.count;
+    }
+    if (d->n_node >= (1u << 30)) return bail(fail(PT_ERR_LIMIT, "more than 2^30 kd nodes"));
+    // ---- per-reference triangle data in node order: v0, v1 - v0, v2 - v0 ----
+    std::vector<double> rt((size_t)d->n_ref * 9);
+    std::vector<float4> rtf((size_t)d->n_ref * 3);
+    for (uint32_t r = 0; r < d->n_ref; r++) {
+        int32_t t = d->refs[r];
+        const double *a = d->vert + 3 * (size_t)d->tri_vi[3 * (size_t)t];
+        const double *b = d->vert + 3 * (size_t)d->tri_vi[3 * (size_t)t + 1];
+        const double *c = d->vert + 3 * (size_t)d->tri_vi[3 * (size_t)t + 2];
+        double *o = &rt[(size_t)r * 9];
+        for (int k = 0; k < 3; k++) { o[k] = a[k]; o[3 + k] = b[k] - a[k]; o[6 + k] = c[k] - a[k]; }
+        rtf[3 * (size_t)r] = make_float4((float)o[0], (float)o[1], (float)o[2], bits_to_float(t));
+        rtf[3 * (size_t)r + 1] = make_float4((float)o[3], (float)o[4], (float)o[5], 0.f);
+        rtf[3 * (size_t)r + 2] = make_float4((float)o[6], (float)o[7], (float)o[8], 0.f);
+    }
+    // ---- textures flattened into one byte pool ----
+    std::vector<int64_t> toff(d->n_tex);
+    std::vector<int32_t> trows(d->n_tex), tcols(d->n_tex);
+    std::vector<uint8_t> texels;
+    for (uint32_t k = 0; k < d->n_tex; k++) {
+        toff[k] = (int64_t)texels.size();
+        trows[k] = d->tex[k].rows; tcols[k] = d->tex[k].cols;
+        size_t nb = (size_t)trows[k] * tcols[k] * 3;
+        texels.insert(texels.end(), d->tex[k].bgr, d->tex[k].bgr + nb);
+    }
+#define UP(expr) do { int rc_ = (expr); if (rc_) return bail(rc_); } while (0)
+    UP(dev_copy(sc, na.data(), na.size(), &S.nodeA));
+    UP(dev_copy(sc, nbox.data(), nbox.size(), &S.nodeBox));
+    UP(dev_copy(sc, nf.data(), nf.size(), &S.nodeF));
+    UP(dev_copy(sc, rt.data(), rt.size(), &S.refTri));
+    UP(dev_copy(sc, rtf.data(), rtf.size(), &S.refTriF));
+    UP(dev_copy(sc, d->refs, (size_t)d->n_ref, &S.refId));
+    UP(dev_copy(sc, d->tri_ni, (size_t)d->n_tri * 3, &S.tri_ni));
+    UP(dev_copy(sc, d->tri_ti, (size_t)d->n_tri * 3, &S.tri_ti));
+    UP(dev_copy(sc, d->tri_tm, (size_t)d->n_tri, &S.tri_tm));
+    UP(dev_copy(sc, d->tri_reft, (size_t)d->n_tri, &S.tri_reft));
+    UP(dev_copy(sc, d->tri_mesh, (size_t)d->n_tri, &S.tri_mesh));
+    UP(dev_copy(sc, d->tri_local, (size_t)d->n_tri, &S.tri_local));
+    UP(dev_copy(sc, d->norm, (size_t)d->n_norm * 3, &S.norm));
+    {
+        std::vector<float> nf32((size_t)d->n_norm * 3), uf32((size_t)d->n_uv * 2);
+        for (size_t k = 0; k < nf32.size(); k++) nf32[k] = (float)d->norm[k];
+        for (size_t k = 0; k < uf32.size(); k++) uf32[k] = (float)d->uv[k];
+        UP(dev_copy(sc, nf32.data(), nf32.size(), &S.normF));
+        UP(dev_copy(sc, uf32.data(), uf32.size(), &S.uvF));
+    }
+    UP(dev_copy(sc, d->uv, (size_t)d->n_uv * 2, &S.uv));
+    UP(dev_copy(sc, d->mesh_albedo, (size_t)d->n_mesh * 3, &S.albedo));
+    UP(dev_copy(sc, texels.data(), texels.size(), &S.texels));
+    UP(dev_copy(sc, toff.data(), toff.size(), &S.tex_off));
+    UP(dev_copy(sc, trows.data(), trows.size(), &S.tex_rows));
+    UP(dev_copy(sc, tcols.data(), tcols.size(), &S.tex_cols));
+    UP(dev_copy(sc, d->lights, (size_t)d->n_light, &S.lights));
+#undef UP
+    S.n_light = (int32_t)d->n_light; S.n_node = (int32_t)d->n_node; S.n_ref = (int32_t)d->n_ref; S.n_tri = (int32_t)d->n_tri;
+    for (int k = 0; k < 3; k++) {
+        S.bg[k] = d->background[k];
+        S.root_lo[k] = d->nodes[0].lo[k];
+        S.root_hi[k] = d->nodes[0].hi[k];
+    }
+    hipError_t e = hipStreamCreate(&sc->stream);
+    if (e == hipSuccess) e = hipEventCreate(&sc->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
+    if (e != hipSuccess) return bail(fail(PT_ERR_HIP, std::string("stream/event creation: ") + hipGetErrorString(e)));
+    *out = sc;
+    return PT_OK;
+}
+
+int ensure_workspace(PtScene *sc, int size, int batch, bool fast) {
+    Workspace &ws = sc->ws;
+    bool have_fast = ws.Q.rays_o != nullptr;
+    if (ws.size == size && ws.batch >= batch && (!fast || have_fast)) return PT_OK;
+    if (batch < ws.batch && ws.size == size) batch = ws.batch;
+    fast = fast || (have_fast && ws.size == size);
+    ws_release(ws);
+    size_t P = (size_t)size * size;
+    FrameBuffers &F = ws.F;
+#define WS(expr) do { int rc_ = (expr); if (rc_) { ws_release(ws); return rc_; } } while (0)
+    WS(ws_alloc(ws, P * 3, &F.mpnt));
+    WS(ws_alloc(ws, P * 3, &F.gclr));
+    WS(ws_alloc(ws, P * 3, &F.gnrm));
+    WS(ws_alloc(ws, P * 3, &F.ghit));
+    WS(ws_alloc(ws, P, &F.rec_found));
+    WS(ws_alloc(ws, P, &F.rec_tri));
+    WS(ws_alloc(ws, P, &F.rec_t));
+    WS(ws_alloc(ws, P, &F.rec_u));
+    WS(ws_alloc(ws, P, &F.rec_v));
+    WS(ws_alloc(ws, P * 3, &F.gi_acc));
+    WS(ws_alloc(ws, P * 3 * (size_t)batch, &F.contrib));
+    WS(ws_alloc(ws, P * 3, &F.rgb));
+    WS(ws_alloc(ws, P * 3, &F.bgr));
+    WS(ws_alloc(ws, (size_t)RC_N, &F.counters));
+    if (fast) WS(fast_alloc(ws.Q, P, batch, ws_alloc_cb, &ws));
+#undef WS
+    ws.size = size; ws.batch = batch;
+    return PT_OK;
+}
+
+int check_options(const PtOptions *o, int *size, int *nsamples) {
+    if (!o) return fail(PT_ERR_INVALID, "options are null");
+    if (o->struct_size != sizeof(PtOptions)) return fail(PT_ERR_INVALID, "PtOptions.struct_size mismatch");
+    if (o->model != PT_MODEL_MAIN && o->model != PT_MODEL_OMP) return fail(PT_ERR_INVALID, "unknown shading model");
+    if (o->gi_precision != PT_GI_F64_EXACT && o->gi_precision != PT_GI_F32_FAST) return fail(PT_ERR_INVALID, "unknown gi_precision");
+    if (o->spp < 0) return fail(PT_ERR_INVALID, "spp is negative");
+    int s = o->size == 0 ? 512 : o->size;
+    if (s < 1 || s > 8192) return fail(PT_ERR_LIMIT, "image size must be in 1..8192");
+    *size = s;
+    *nsamples = o->spp > 0 ? o->spp : (o->model == PT_MODEL_MAIN ? 4 : 16);   // main.cpp:129, mainOMP.cpp:132
+    return PT_OK;
+}
+
+// One view on the scene's stream; leaves the frame in ws.F (bgr, rgb, AOVs).
+int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtStats *st, float *gi_ms, uint64_t *gi_launches) {
+    int size, N;
+    int rc = check_options(o, &size, &N);
+    if (rc) return rc;
+    if (!cam) return fail(PT_ERR_INVALID, "camera is null");
+    const bool fast = o->gi && o->gi_precision == PT_GI_F32_FAST;
+    size_t P = (size_t)size * size;
+    // samples per GI pass: bounded so that per-pass buffers stay at a few hundred MB
+    int batch = 1;
+    if (o->gi) {
+        size_t cap = fast ? (size_t)PT_FAST_RAYS_PER_PASS : ((size_t)16 << 18);
+        batch = (int)(cap / P);
+        if (batch < 1) batch = 1;
+        if (batch > N) batch = N;
+    }
+    rc = ensure_workspace(sc, size, batch, fast);
+    if (rc) return rc;
+    FrameBuffers &F = sc->ws.F;
+    ViewParams V{};
+    for (int k = 0; k < 3; k++) V.eye[k] = cam->eye[k];
+    V.zoom = cam->zoom;
+    V.sa = std::sin(cam->angle);
+    V.ca = std::cos(cam->angle);
+    V.size = size; V.rb = o->rb ? 1 : 0;
+    V.off = o->model == PT_MODEL_MAIN ? 0.01 : 0.1;
+    V.seed = o->seed; V.view = o->view; V.model = o->model;
+    hipStream_t s = sc->stream;
+    HIPCHK(hipMemsetAsync(F.counters, 0, RC_N * sizeof(unsigned long long), s));
+    if (exact_primary(sc->S, V, F, s)) return fail(PT_ERR_HIP, "primary pass launch failed");
+    *gi_ms = 0; *gi_launches = 0;
+    uint64_t fast_rays = 0, fast_shadow = 0;
+    if (o->gi) {
+        if (fast) {
+            rc = fast_gi(sc->S, V, F, sc->ws.Q, N, batch, s, sc->ev0, sc->ev1, gi_ms, gi_launches, &fast_rays, &fast_shadow);
+            if (rc) return fail(rc, std::string("GI wavefront pass failed: ") + hipGetErrorString(hipGetLastError()));
+        } else {
+            for (int s0 = 0; s0 < N; s0 += batch) {
+                int nb = N - s0 < batch ? N - s0 : batch;
+                HIPCHK(hipEventRecord(sc->ev0, s));
+                if (exact_gi(sc->S, V, F, s0, nb, s)) return fail(PT_ERR_HIP, "GI pass launch failed");
+                HIPCHK(hipEventRecord(sc->ev1, s));
+                if (gi_accumulate(F, size, nb, s0 == 0, s)) return fail(PT_ERR_HIP, "GI accumulation launch failed");
+                HIPCHK(hipEventSynchronize(sc->ev1));
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
+                *gi_ms += ms; (*gi_launches)++;
+            }
+        }
+    }
+    if (resolve_frame(F, size, o->gi ? 1 : 0, N, s)) return fail(PT_ERR_HIP, "resolve launch failed");
+    if (st) {
+        unsigned long long c[RC_N];
+        HIPCHK(hipMemcpyAsync(c, F.counters, sizeof c, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        st->primary += c[RC_PRIMARY]; st->shadow += c[RC_SHADOW]; st->mirror += c[RC_MIRROR];
+        st->gi += c[RC_GI] + fast_rays; st->shadow += fast_shadow; st->omp_retrace += c[RC_RETRACE];
+        st->ms_gi_trace += *gi_ms; st->gi_trace_launches += *gi_launches;
+    }
+    return PT_OK;
+}
+
+template <typename T>
+int fetch(PtScene *sc, T *host, const T *dev, size_t n) {
+    if (!host) return PT_OK;
+    HIPCHK(hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, sc->stream));
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pt_last_error(void) { return g_error.c_str(); }
+const char *pt_version(void) { return "pathtracing_amd 0.1 (gfx950)"; }
+
+int pt_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device is visible");
+    int dev = device < 0 ? 0 : device;
+    if (dev >= n) return fail(PT_ERR_NO_DEVICE, "device ordinal " + std::to_string(dev) + " out of range (" + std::to_string(n) + " visible)");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    HIPCHK(hipSetDevice(dev));
+    g_device = dev;
+    return PT_OK;
+}
+
+int pt_shutdown(void) { g_device = -1; return PT_OK; }
+
+int pt_scene_upload(const PtSceneDesc *desc, PtScene **out) { return upload(desc, out); }
+
+int pt_scene_free(PtScene *sc) {
+    if (!sc) return PT_OK;
+    ws_release(sc->ws);
+    for (void *p : sc->owned) (void)hipFree(p);
+    if (sc->ev0) (void)hipEventDestroy(sc->ev0);
+    if (sc->ev1) (void)hipEventDestroy(sc->ev1);
+    if (sc->stream) (void)hipStreamDestroy(sc->stream);
+    delete sc;
+    return PT_OK;
+}
+
+// ---- blob form: header, then the arrays of PtSceneDesc back to back (8-byte aligned) ----
+struct BlobHeader {
+    char magic[8];            // "PTBLOB01"
+    uint32_t counts[9];       // n_mesh .. n_ref in PtSceneDesc order
+    uint32_t reserved;
+    double background[3];
+    uint64_t total_bytes;
+};
+
+static size_t pad8(size_t n) { return (n + 7) & ~(size_t)7; }
+
+static size_t blob_bytes(const PtSceneDesc *d) {
+    size_t n = sizeof(BlobHeader);
+    n += pad8((size_t)d->n_vert * 24) + pad8((size_t)d->n_norm * 24) + pad8((size_t)d->n_uv * 16);
+    n += 3 * pad8((size_t)d->n_tri * 12) + 4 * pad8((size_t)d->n_tri * 4);
+    n += pad8((size_t)d->n_mesh * 24);
+    n += pad8((size_t)d->n_tex * 8);
+    for (uint32_t k = 0; k < d->n_tex; k++) n += pad8((size_t)d->tex[k].rows * d->tex[k].cols * 3);
+    n += pad8((size_t)d->n_light * sizeof(PtLight));
+    n += pad8((size_t)d->n_node * sizeof(PtKdNode)) + pad8((size_t)d->n_ref * 4);
+    return n;
+}
+
+int pt_scene_blob_size(const PtSceneDesc *desc, size_t *bytes) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    if (!bytes) return fail(PT_ERR_INVALID, "bytes pointer is null");
+    *bytes = blob_bytes(desc);
+    return PT_OK;
+}
+
+int pt_scene_blob_write(const PtSceneDesc *d, void *blob, size_t bytes) {
+    int rc = validate_desc(d);
+    if (rc) return rc;
+    if (!blob || bytes < blob_bytes(d)) return fail(PT_ERR_INVALID, "blob buffer too small");
+    uint8_t *p = (uint8_t *)blob;
+    std::memset(p, 0, blob_bytes(d));
+    BlobHeader h{};
+    std::memcpy(h.magic, "PTBLOB01", 8);
+    const uint32_t c[9] = {d->n_mesh, d->n_vert, d->n_norm, d->n_uv, d->n_tri, d->n_tex, d->n_light, d->n_node, d->n_ref};
+    std::memcpy(h.counts, c, sizeof c);
+    for (int k = 0; k < 3; k++) h.background[k] = d->background[k];
+    h.total_bytes = blob_bytes(d);
+    std::memcpy(p, &h, sizeof h);
+    size_t o = sizeof h;
+    auto put = [&](const void *src, size_t n) { if (n) std::memcpy(p + o, src, n); o += pad8(n); };
+    put(d->vert, (size_t)d->n_vert * 24); put(d->norm, (size_t)d->n_norm * 24); put(d->uv, (size_t)d->n_uv * 16);
+    put(d->tri_vi, (size_t)d->n_tri * 12); put(d->tri_ni, (size_t)d->n_tri * 12); put(d->tri_ti, (size_t)d->n_tri * 12);
+    put(d->tri_tm, (size_t)d->n_tri * 4); put(d->tri_reft, (size_t)d->n_tri * 4);
+    put(d->tri_mesh, (size_t)d->n_tri * 4); put(d->tri_local, (size_t)d->n_tri * 4);
+    put(d->mesh_albedo, (size_t)d->n_mesh * 24);
+    std::vector<int32_t> dims(2 * (size_t)d->n_tex);
+    for (uint32_t k = 0; k < d->n_tex; k++) { dims[2 * k] = d->tex[k].rows; dims[2 * k + 1] = d->tex[k].cols; }
+    put(dims.data(), dims.size() * 4);
+    for (uint32_t k = 0; k < d->n_tex; k++) put(d->tex[k].bgr, (size_t)d->tex[k].rows * d->tex[k].cols * 3);
+    put(d->lights, (size_t)d->n_light * sizeof(PtLight));
+    put(d->nodes, (size_t)d->n_node * sizeof(PtKdNode));
+    put(d->refs, (size_t)d->n_ref * 4);
+    return PT_OK;
+}
+
+int pt_scene_upload_blob(const void *blob, size_t bytes, PtScene **out) {
+    if (!blob || bytes < sizeof(BlobHeader)) return fail(PT_ERR_INVALID, "blob too small");
+    const uint8_t *p = (const uint8_t *)blob;
+    BlobHeader h;
+    std::memcpy(&h, p, sizeof h);
+    if (std::memcmp(h.magic, "PTBLOB01", 8) != 0 || h.total_bytes > bytes) return fail(PT_ERR_INVALID, "not a scene blob, or truncated");
+    PtSceneDesc d{};
+    d.struct_size = sizeof d;
+    d.n_mesh = h.counts[0]; d.n_vert = h.counts[1]; d.n_norm = h.counts[2]; d.n_uv = h.counts[3]; d.n_tri = h.counts[4];
+    d.n_tex = h.counts[5]; d.n_light = h.counts[6]; d.n_node = h.counts[7]; d.n_ref = h.counts[8];
+    for (int k = 0; k < 3; k++) d.background[k] = h.background[k];
+    size_t o = sizeof h;
+    bool ok = true;
+    auto take = [&](size_t n) -> const void * {
+        const void *q = p + o;
+        if (o + pad8(n) > h.total_bytes) { ok = false; return p; }
+        o += pad8(n);
+        return q;
+    };
+    d.vert = (const double *)take((size_t)d.n_vert * 24); d.norm = (const double *)take((size_t)d.n_norm * 24);
+    d.uv = (const double *)take((size_t)d.n_uv * 16);
+    d.tri_vi = (const int32_t *)take((size_t)d.n_tri * 12); d.tri_ni = (const int32_t *)take((size_t)d.n_tri * 12);
+    d.tri_ti = (const int32_t *)take((size_t)d.n_tri * 12);
+    d.tri_tm = (const int32_t *)take((size_t)d.n_tri * 4); d.tri_reft = (const int32_t *)take((size_t)d.n_tri * 4);
+    d.tri_mesh = (const int32_t *)take((size_t)d.n_tri * 4); d.tri_local = (const int32_t *)take((size_t)d.n_tri * 4);
+    d.mesh_albedo = (const double *)take((size_t)d.n_mesh * 24);
+    const int32_t *dims = (const int32_t *)take((size_t)d.n_tex * 8);
+    std::vector<PtTexture> tex(d.n_tex);
+    for (uint32_t k = 0; ok && k < d.n_tex; k++) {
+        tex[k].rows = dims[2 * k]; tex[k].cols = dims[2 * k + 1];
+        if (tex[k].rows <= 0 || tex[k].cols <= 0) { ok = false; break; }
+        tex[k].bgr = (const uint8_t *)take((size_t)tex[k].rows * tex[k].cols * 3);
+    }
+    d.tex = tex.data();
+    d.lights = (const PtLight *)take((size_t)d.n_light * sizeof(PtLight));
+    d.nodes = (const PtKdNode *)take((size_t)d.n_node * sizeof(PtKdNode));
+    d.refs = (const int32_t *)take((size_t)d.n_ref * 4);
+    if (!ok) return fail(PT_ERR_INVALID, "scene blob is truncated");
+    return upload(&d, out);
+}
+
+int pt_render_view(PtScene *sc, const PtCamera *cam, const PtOptions *opt, uint8_t *bgr_out, PtAov *aov, PtStats *stats) {
+    if (!sc) return fail(PT_ERR_INVALID, "scene is null");
+    auto t0 = std::chrono::steady_clock::now();
+    float gi_ms; uint64_t gi_l;
+    int rc = render_on_device(sc, cam, opt, stats, &gi_ms, &gi_l);
+    if (rc) return rc;
+    size_t P = (size_t)sc->ws.size * sc->ws.size;
+    FrameBuffers &F = sc->ws.F;
+    std::vector<int32_t> tri;
+    rc = fetch(sc, bgr_out, F.bgr, P * 3);
+    if (rc) return rc;
+    if (aov) {
+        if (aov->mesh || aov->tri) { tri.resize(P); rc = fetch(sc, tri.data(), F.rec_tri, P); if (rc) return rc; }
+        if ((rc = fetch(sc, aov->t, F.rec_t, P)) || (rc = fetch(sc, aov->u, F.rec_u, P)) || (rc = fetch(sc, aov->v, F.rec_v, P)) ||
+            (rc = fetch(sc, aov->rgb, F.rgb, P * 3)) || (rc = fetch(sc, aov->gclr, F.gclr, P * 3)) ||
+            (rc = fetch(sc, aov->gnrm, F.gnrm, P * 3)) || (rc = fetch(sc, aov->ghit, F.ghit, P * 3)))
+            return rc;
+    }
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    if (aov && (aov->mesh || aov->tri))
+        for (size_t p = 0; p < P; p++) {
+            int32_t t = tri[p];
+            if (aov->mesh) aov->mesh[p] = t < 0 ? -1 : sc->tri_mesh[t];
+            if (aov->tri) aov->tri[p] = t < 0 ? -1 : sc->tri_local[t];
+        }
+    if (stats) stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PT_OK;
+}
+
+int pt_render_view_device(PtScene *sc, const PtCamera *cam, const PtOptions *opt, void *d_bgr, PtStats *stats) {
+    if (!sc || !d_bgr) return fail(PT_ERR_INVALID, "scene or output pointer is null");
+    auto t0 = std::chrono::steady_clock::now();
+    float gi_ms; uint64_t gi_l;
+    int rc = render_on_device(sc, cam, opt, stats, &gi_ms, &gi_l);
+    if (rc) return rc;
+    size_t P = (size_t)sc->ws.size * sc->ws.size;
+    HIPCHK(hipMemcpyAsync(d_bgr, sc->ws.F.bgr, P * 3, hipMemcpyDeviceToDevice, sc->stream));
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    if (stats) stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PT_OK;
+}
+
+int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0, uint32_t view_stride,
+                    const PtOptions *opt, uint8_t *frames, PtStats *stats) {
+    if (!sc || (n && (!cams || !frames))) return fail(PT_ERR_INVALID, "scene, cameras or frames pointer is null");
+    int size, N;
+    int rc = check_options(opt, &size, &N);
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    size_t frame_bytes = (size_t)size * size * 3;
+    PtOptions o = *opt;
+    for (size_t i = 0; i < n; i++) {
+        o.view = view0 + (uint32_t)i * view_stride;
+        float gi_ms; uint64_t gi_l;
+        rc = render_on_device(sc, &cams[i], &o, stats, &gi_ms, &gi_l);
+        if (rc) return rc;
+        // the copy is ordered on the scene's stream; the next view's kernels follow it
+        HIPCHK(hipMemcpyAsync(frames + i * frame_bytes, sc->ws.F.bgr, frame_bytes, hipMemcpyDeviceToHost, sc->stream));
+    }
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    if (stats) stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PT_OK;
+}
+
+int pt_trace(PtScene *sc, size_t n, const double *src, const double *dir, const double *tmin_in, int mode,
+             int32_t *found, int32_t *mesh, int32_t *tri, double *t, double *u, double *v) {
+    if (!sc) return fail(PT_ERR_INVALID, "scene is null");
+    if (mode != 0 && mode != 1) return fail(PT_ERR_INVALID, "pt_trace: mode must be 0 or 1");
+    if (n == 0) return PT_OK;
+    if (!src || !dir || !tmin_in || !found || !mesh || !tri || !t || !u || !v) return fail(PT_ERR_INVALID, "pt_trace: null array");
+    if (n > ((size_t)1 << 28)) return fail(PT_ERR_LIMIT, "pt_trace: more than 2^28 rays in one call");
+    double *d_src = nullptr, *d_dir = nullptr, *d_tmin = nullptr, *d_t = nullptr, *d_u = nullptr, *d_v = nullptr;
+    int32_t *d_found = nullptr, *d_tri = nullptr;
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+    auto alloc = [&](void **p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) tmp.push_back(*p);
+        return e;
+    };
+#define TR(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    TR(alloc((void **)&d_src, n * 24)); TR(alloc((void **)&d_dir, n * 24)); TR(alloc((void **)&d_tmin, n * 8));
+    TR(alloc((void **)&d_t, n * 8)); TR(alloc((void **)&d_u, n * 8)); TR(alloc((void **)&d_v, n * 8));
+    TR(alloc((void **)&d_found, n * 4)); TR(alloc((void **)&d_tri, n * 4));
+    hipStream_t s = sc->stream;
+    TR(hipMemcpyAsync(d_src, src, n * 24, hipMemcpyHostToDevice, s));
+    TR(hipMemcpyAsync(d_dir, dir, n * 24, hipMemcpyHostToDevice, s));
+    TR(hipMemcpyAsync(d_tmin, tmin_in, n * 8, hipMemcpyHostToDevice, s));
+    if ((mode == 0 ? exact_trace : fast_trace)(sc->S, n, d_src, d_dir, d_tmin, d_found, d_tri, d_t, d_u, d_v, s)) {
+        cleanup();
+        return fail(PT_ERR_HIP, std::string("pt_trace launch: ") + hipGetErrorString(hipGetLastError()));
+    }
+    TR(hipMemcpyAsync(found, d_found, n * 4, hipMemcpyDeviceToHost, s));
+    TR(hipMemcpyAsync(tri, d_tri, n * 4, hipMemcpyDeviceToHost, s));
+    TR(hipMemcpyAsync(t, d_t, n * 8, hipMemcpyDeviceToHost, s));
+    TR(hipMemcpyAsync(u, d_u, n * 8, hipMemcpyDeviceToHost, s));
+    TR(hipMemcpyAsync(v, d_v, n * 8, hipMemcpyDeviceToHost, s));
+    TR(hipStreamSynchronize(s));
+#undef TR
+    cleanup();
+    for (size_t k = 0; k < n; k++) {
+        int32_t g = tri[k];
+        mesh[k] = g < 0 ? -1 : sc->tri_mesh[g];
+        tri[k] = g < 0 ? -1 : sc->tri_local[g];
+    }
+    return PT_OK;
+}
+
+int pt_camera_rays(const PtCamera *cam, int size, double x, double y, double *dir_out) {
+    if (g_device < 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not been called");
+    if (!cam || !dir_out || size < 1 || size > 8192) return fail(PT_ERR_INVALID, "pt_camera_rays: bad argument");
+    size_t P = (size_t)size * size;
+    double *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, P * 24));
+    ViewParams V{};
+    for (int k = 0; k < 3; k++) V.eye[k] = cam->eye[k];
+    V.zoom = cam->zoom; V.sa = std::sin(cam->angle); V.ca = std::cos(cam->angle); V.size = size;
+    int lrc = camera_rays(V, x, y, d, 0);
+    hipError_t e = lrc ? hipErrorLaunchFailure : hipMemcpy(dir_out, d, P * 24, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PT_ERR_HIP, std::string("pt_camera_rays: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+int pt_hemisphere_samples(uint32_t seed, uint32_t view, uint32_t pixel, int n, double *out) {
+    if (g_device < 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not been called");
+    if (!out || n < 1 || n > (1 << 24)) return fail(PT_ERR_INVALID, "pt_hemisphere_samples: bad argument");
+    double *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, (size_t)n * 24));
+    int lrc = hemisphere_samples(seed, view, pixel, n, d, 0);
+    hipError_t e = lrc ? hipErrorLaunchFailure : hipMemcpy(out, d, (size_t)n * 24, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PT_ERR_HIP, std::string("pt_hemisphere_samples: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+// fp64 device functions with the reference's exact semantics: ray/triangle
+// test, kd search, surface properties, lights, castRay.  A thread owns a ray
+// from search to radiance; the traversal stack is a per-lane array.
+#pragma once
+#include <float.h>
+
+#include "pt_scene_dev.h"
+#include "pt_vec.h"
+
+#define PT_STACK_MAX 64   // >= tree depth, checked when the scene is uploaded
+
+struct HitD { int32_t tri; double tmin, u, v; };
+
+struct RayCounts { uint32_t n[RC_N]; };
+
+// Moeller-Trumbore as util/polygonMesh.cpp:54-74 (two-sided, three divides).
+// v0, e1 = v1 - v0, e2 = v2 - v0 are precomputed in fp64 on the host with the
+// same subtractions the reference performs per call.
+PT_DEV bool tri_intersect(const double *__restrict__ T9, const RayD &ray, double &t, double &bu, double &bv) {
+    D3 v0 = dload(T9), ba = dload(T9 + 3), ca = dload(T9 + 6);
+    D3 P = dcross(ray.dir, ca);
+    double det = ddot(P, ba);
+    D3 T = dsub(ray.src, v0);
+    double u = ddot(P, T) / det;
+    if (u < 0.0 || u > 1.0) return false;
+    D3 Q = dcross(T, ba);
+    double v = ddot(Q, ray.dir) / det;
+    if (v < 0.0 || u + v > 1.0) return false;
+    t = ddot(Q, ca) / det;
+    bu = u; bv = v;
+    return true;
+}
+
+// Box::intersect, util/kdtree.cpp:30-49 (ent/ext come from the x and y slabs only).
+PT_DEV bool box_intersect(const double lo[3], const double hi[3], const RayD &r, double &ent, double &ext) {
+    double tmin = ((r.sx ? hi[0] : lo[0]) - r.src.x) * r.inv.x;
+    double tmax = ((r.sx ? lo[0] : hi[0]) - r.src.x) * r.inv.x;
+    double ymin = ((r.sy ? hi[1] : lo[1]) - r.src.y) * r.inv.y;
+    double ymax = ((r.sy ? lo[1] : hi[1]) - r.src.y) * r.inv.y;
+    if ((tmin > ymax) || (ymin > tmax)) return false;
+    if (ymin > tmin) tmin = ymin;
+    if (ymax < tmax) tmax = ymax;
+    double zmin = ((r.sz ? hi[2] : lo[2]) - r.src.z) * r.inv.z;
+    double zmax = ((r.sz ? lo[2] : hi[2]) - r.src.z) * r.inv.z;
+    if ((tmin > zmax) || (zmin > tmax)) return false;
+    ent = tmin; ext = tmax;
+    return true;
+}
+
+// KDNode::searchNode, util/kdtree.cpp:180-197: a hit only counts when the hit
+// point lies inside the node's own box (inclusive on all three axes).
+PT_DEV bool search_node(const DevScene &S, int node, const NodeA &na, const RayD &ray, HitD &h) {
+    bool found = false;
+    const double *tri = S.refTri + (size_t)na.first * 9;
+    for (int i = 0; i < na.count; i++, tri += 9) {
+        double t, bu, bv;
+        if (tri_intersect(tri, ray, t, bu, bv) && t > 0 && t < h.tmin) {
+            D3 hit = dadd(ray.src, dscale(t, ray.dir));
+            const double *b = S.nodeBox + (size_t)node * 6;
+            if (!(hit.x >= b[0] && hit.y >= b[1] && hit.z >= b[2] && hit.x <= b[3] && hit.y <= b[4] && hit.z <= b[5]))
+                continue;
+            found = true;
+            h.tmin = t; h.u = bu; h.v = bv;
+            h.tri = S.refId[na.first + i];
+        }
+    }
+    return found;
+}
+
+// search(), util/kdtree.cpp:216-257.  h.tmin is the in/out bound.
+PT_DEV bool search_ref(const DevScene &S, const RayD &ray, HitD &h) {
+    double ent, ext;
+    if (!box_intersect(S.root_lo, S.root_hi, ray, ent, ext)) return false;
+    int32_t sn[PT_STACK_MAX];
+    double se[PT_STACK_MAX], sx[PT_STACK_MAX];
+    int sp = 0;
+    sn[0] = 0; se[0] = ent; sx[0] = ext; sp = 1;
+    bool found = false;
+    while (sp > 0) {
+        sp--;
+        int curr = sn[sp];
+        ent = se[sp]; ext = sx[sp];
+        if (ent >= h.tmin) break;
+        NodeA na = S.nodeA[curr];
+        while (na.axis >= 0) {
+            if (na.count > 0) found |= search_node(S, curr, na, ray, h);
+            double s = na.split;
+            int a = na.axis;
+            double da = dget(ray.dir, a), sa = dget(ray.src, a);
+            double tdir = da == 0 ? 0.0000001 : da;
+            double tmid = (s - sa) / tdir;
+            int nr = na.left, fr = na.left + 1;
+            if (sa > s) { int x = nr; nr = fr; fr = x; }
+            if (tmid >= ext || tmid < 0)
+                curr = nr;
+            else if (tmid <= ent && tmid <= h.tmin)
+                curr = fr;
+            else {
+                if (tmid <= h.tmin && sp < PT_STACK_MAX) { sn[sp] = fr; se[sp] = tmid; sx[sp] = ext; sp++; }
+                curr = nr;
+                ext = tmid;
+            }
+            na = S.nodeA[curr];
+        }
+        if (na.count > 0 && search_node(S, curr, na, ray, h)) return true;
+    }
+    return found;
+}
+
+// ---- shading ------------------------------------------------------------------
+
+PT_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// cv::Mat::at<Vec3b>(Point(x, y)) is row y, column x; indices are clamped into
+// the image (the reference does not check them).
+PT_DEV const uint8_t *texel(const DevScene &S, int tex, int px, int py) {
+    int rows = S.tex_rows[tex], cols = S.tex_cols[tex];
+    int row = clampi(py, 0, rows - 1), col = clampi(px, 0, cols - 1);
+    return S.texels + S.tex_off[tex] + ((size_t)row * cols + col) * 3;
+}
+
+// PolygonMesh::surfaceProperties, util/polygonMesh.cpp:81-118.
+PT_DEV void surface_properties(const DevScene &S, int tri, double bu, double bv, D3 &nrm, D3 &txt, int &reft) {
+    const int32_t *N = S.tri_ni + (size_t)tri * 3;
+    double w = 1.0 - bu - bv;
+    D3 n0 = dload(S.norm + (size_t)N[0] * 3), n1 = dload(S.norm + (size_t)N[1] * 3), n2 = dload(S.norm + (size_t)N[2] * 3);
+    nrm = dunit(dadd(dadd(dscale(w, n0), dscale(bu, n1)), dscale(bv, n2)));
+    int mn = S.tri_tm[tri];
+    reft = S.tri_reft[tri];
+    if (mn == -99999) { txt = d3(1, 1, 1); return; }
+    const int32_t *T = S.tri_ti + (size_t)tri * 3;
+    if (mn < 0) {
+        mn = -(mn + 1);
+        int rows = S.tex_rows[mn];
+        const double *a = S.uv + (size_t)T[0] * 2, *b = S.uv + (size_t)T[1] * 2, *c = S.uv + (size_t)T[2] * 2;
+        int r = (int)((a[0] * w + b[0] * bu + c[0] * bv) * rows);
+        int cc = (int)((a[1] * w + b[1] * bu + c[1] * bv) * rows);
+        const uint8_t *p = texel(S, mn, r, cc);
+        txt = ddivs(d3((double)p[2], (double)p[1], (double)p[0]), 256.0);
+    } else {
+        int rows = S.tex_rows[mn], cols = S.tex_cols[mn];
+        D3 col[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            int r = 0, c = 0;
+            if (T[i] != -1) {
+                r = (int)(S.uv[(size_t)T[i] * 2] * rows);
+                c = (int)(S.uv[(size_t)T[i] * 2 + 1] * cols);
+            }
+            int px = r < 0 ? 0 : r; if (px > rows) px = rows;
+            int py = c < 0 ? 0 : c; if (py > cols) py = cols;
+            const uint8_t *p = texel(S, mn, px, py);
+            col[i] = d3((double)p[2], (double)p[1], (double)p[0]);
+        }
+        txt = ddivs(dadd(dadd(dscale(w, col[0]), dscale(bu, col[1])), dscale(bv, col[2])), 256.0);
+    }
+}
+
+// Light::illuminate, util/lighting.cpp:24-36.
+PT_DEV void illuminate(const PtLight &L, D3 hit, D3 &ldir, D3 &shade, double &dis) {
+    D3 pos = d3(L.pos[0], L.pos[1], L.pos[2]), color = d3(L.color[0], L.color[1], L.color[2]);
+    ldir = d3(0, 0, 0); shade = d3(0, 0, 0); dis = 0;
+    if (L.type == 'd') {
+        dis = (double)FLT_MAX;
+        ldir = dunit(pos);
+        shade = dscale(L.mag, color);
+    } else if (L.type == 'p') {
+        ldir = dsub(pos, hit);
+        dis = dlen(ldir);
+        ldir = dunit(ldir);
+        shade = ddivs(dscale(L.mag, color), 4 * dis * 3.14159265358979323846);
+    }
+}
+
+// createCoordSystem, util/lighting.cpp:42-48.
+PT_DEV void coord_system(D3 N, D3 &Nt, D3 &Nb) {
+    if (fabs(N.x) > fabs(N.y))
+        Nt = ddivs(d3(N.z, 0, -N.x), sqrt(N.x * N.x + N.z * N.z));
+    else
+        Nt = ddivs(d3(0, -N.z, N.y), sqrt(N.y * N.y + N.z * N.z));
+    Nb = dcross(N, Nt);
+}
+
+struct GBufD { D3 clr, nrm, hit; };
+
+// Primary-hit record of the depth-0 call.
+struct PrimRec { int32_t found, tri; double t, u, v; };
+
+// castRay of main.cpp:41-78 (MODEL == PT_MODEL_MAIN) and mainOMP.cpp:37-78
+// (PT_MODEL_OMP).  depth: 0 primary, 1 MAIN's mirror bounce, -1 GI sample ray
+// or OMP's mirror bounce.  PRIMARY selects the depth-0 form, which evaluates its
+// one mirror bounce in line through the non-primary instantiation.
+template <int MODEL, bool PRIMARY>
+PT_DEV D3 cast_ray(const DevScene &S, const RayD &ray, int depth, GBufD *g, PrimRec *rec, RayCounts &rc) {
+    HitD h; h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
+    bool ok = search_ref(S, ray, h);
+    if (rec) { rec->found = ok; rec->tri = h.tri; rec->t = h.tmin; rec->u = h.u; rec->v = h.v; }
+    if (!ok) {
+        if (depth == 0) {
+            if (g) g->hit = d3(-99999, -99999, -99999);
+            return d3(S.bg[0], S.bg[1], S.bg[2]);
+        }
+        return d3(0, 0, 0);
+    }
+    D3 nrm, txt; int reft;
+    surface_properties(S, h.tri, h.u, h.v, nrm, txt, reft);
+    D3 hit = dadd(dadd(ray.src, dscale(h.tmin, ray.dir)), dscale(0.0001, nrm));
+    D3 direct = d3(0, 0, 0), ref = d3(0, 0, 0);
+    for (int k = 0; k < S.n_light; k++) {
+        D3 ldir, shade; double dis;
+        illuminate(S.lights[k], hit, ldir, shade, dis);
+        bool vis;
+        if (MODEL == PT_MODEL_MAIN) {                        // main.cpp:62-63: a real shadow ray
+            RayD lray = make_ray(hit, ldir);
+            HitD sh; sh.tmin = dis; sh.tri = -1; sh.u = 0; sh.v = 0;
+            vis = !search_ref(S, lray, sh);
+            rc.n[RC_SHADOW]++;
+        } else {                                             // mainOMP.cpp:60: re-traces `ray` bounded by its own hit
+            vis = !search_ref(S, ray, h);
+            rc.n[RC_RETRACE]++;
+        }
+        double cosv = ddot(ldir, nrm);
+        double mx = (0.0 < cosv) ? cosv : 0.0;
+        direct = dadd(direct, dscale((vis ? 1.0 : 0.0) * mx, shade));
+    }
+    const double *ap = S.albedo + (size_t)S.tri_mesh[h.tri] * 3;
+    D3 alb = d3(ap[0], ap[1], ap[2]);
+    if constexpr (PRIMARY) {
+        if (g) { g->clr = dmul(txt, alb); g->hit = hit; g->nrm = nrm; }
+        if (reft) {
+            RayD rray = make_ray(hit, dreflect(ray.dir, nrm));
+            rc.n[RC_MIRROR]++;
+            ref = dadd(ref, cast_ray<MODEL, false>(S, rray, MODEL == PT_MODEL_MAIN ? 1 : -1, nullptr, nullptr, rc));
+        }
+    }
+    if (MODEL == PT_MODEL_OMP && depth == -1)
+        return ddivs(dmul(dmul(txt, alb), direct), 3.14159265358979323846);        // mainOMP.cpp:74-75
+    D3 a = ddivs(dmul(dmul(dscale(0.6, txt), alb), direct), 3.14159265358979323846); // main.cpp:77, mainOMP.cpp:76
+    return dadd(a, dscale(0.4, ref));
+}
+
+// Camera ray of main.cpp:119-121 / mainOMP.cpp:121-123; sa, ca = sin, cos of the
+// view angle, computed once on the host with libm as the reference does.
+PT_DEV RayD camera_ray(D3 src, double zoom, double sa, double ca, int rows, int i, int j, double x, double y) {
+    D3 pxl = d3(0.5 - (double)(j + x) / rows, 0.5 - (double)(i + y) / rows, zoom);
+    D3 snk = d3(src.x + sa * pxl.x + ca * pxl.z, src.y + pxl.y, src.z - ca * pxl.x + sa * pxl.z);
+    return make_ray(src, dunit(dsub(snk, src)));
+}

@@ -1,0 +1,203 @@
+// Kernels of the fp64 reference-semantics path: one thread per pixel for the
+// primary pass (all of castRay at depth 0, sub-rays of a bundle in sequence so
+// that sums keep the reference's order), one thread per (pixel, sample) for
+// the GI pass, an ordered accumulation and the final quantisation.
+// Build with -ffp-contract=off.
+#include "pt_exact.h"
+#include "pt_frame.h"
+
+// 8x8 pixel tiles: one wave = one tile, so that the rays of a wave stay close.
+PT_DEV bool tile_pixel(int linear, int size, int &i, int &j) {
+    int tiles_x = (size + 7) >> 3;
+    int tile = linear >> 6, lane = linear & 63;
+    int ti = tile / tiles_x, tj = tile - ti * tiles_x;
+    i = ti * 8 + (lane >> 3);
+    j = tj * 8 + (lane & 7);
+    return i < size && j < size;
+}
+
+PT_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+PT_DEV void flush_counts(const RayCounts &rc, unsigned long long *counters) {
+#pragma unroll
+    for (int k = 0; k < RC_N; k++) {
+        uint32_t s = wave_sum(rc.n[k]);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&counters[k], (unsigned long long)s);
+    }
+}
+
+template <int MODEL>
+__global__ void __launch_bounds__(64) k_primary_exact(DevScene S, ViewParams V, FrameBuffers F) {
+    int i, j;
+    RayCounts rc;
+#pragma unroll
+    for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
+    bool live = tile_pixel(blockIdx.x * 64 + threadIdx.x, V.size, i, j);
+    if (live) {
+        size_t p = (size_t)i * V.size + j;
+        D3 src = d3(V.eye[0], V.eye[1], V.eye[2]);
+        D3 paint = d3(0, 0, 0);
+        GBufD g;
+        g.clr = d3(0, 0, 0); g.nrm = d3(0, 0, 0); g.hit = d3(0, 0, 0);
+        PrimRec rec; rec.found = 0; rec.tri = -1; rec.t = -1; rec.u = 0; rec.v = 0;
+        const double off = V.off;
+        for (double y = -off; y <= off; y += off)
+            for (double x = -off; x <= off; x += off) {
+                if (!V.rb && (x != 0 || y != 0)) continue;
+                RayD ray = camera_ray(src, V.zoom, V.sa, V.ca, V.size, i, j, x, y);
+                // MAIN: every sub-ray writes the pixel's G-buffer, the last one wins (main.cpp:68-70);
+                // OMP: only the centre ray does (mainOMP.cpp:124-127).
+                bool owner = (MODEL == PT_MODEL_MAIN) || (x == 0 && y == 0);
+                GBufD scratch;
+                PrimRec rscr;
+                rc.n[RC_PRIMARY]++;
+                paint = dadd(paint, cast_ray<MODEL, true>(S, ray, 0, owner ? &g : &scratch, owner ? &rec : &rscr, rc));
+            }
+        if (V.rb) paint = ddivs(paint, 9.0);
+        dstore(F.mpnt + 3 * p, paint);
+        dstore(F.gclr + 3 * p, g.clr); dstore(F.gnrm + 3 * p, g.nrm); dstore(F.ghit + 3 * p, g.hit);
+        F.rec_found[p] = rec.found; F.rec_tri[p] = rec.found ? rec.tri : -1;
+        F.rec_t[p] = rec.found ? rec.t : -1.0; F.rec_u[p] = rec.u; F.rec_v[p] = rec.v;
+    }
+    flush_counts(rc, F.counters);
+}
+
+// globalIllumination, main.cpp:85-101 / mainOMP.cpp:85-101, one sample per thread.
+// Thread t of the launch handles sample s0 + t / tile_threads and the pixel of
+// t % tile_threads; contrib holds r1 * castRay(iray, -1) in sample order.
+template <int MODEL>
+__global__ void __launch_bounds__(64) k_gi_exact(DevScene S, ViewParams V, FrameBuffers F, int s0, int tthreads) {
+    int lin = blockIdx.x * 64 + threadIdx.x;
+    int sl = lin / tthreads;
+    int i, j;
+    RayCounts rc;
+#pragma unroll
+    for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
+    bool live = tile_pixel(lin - sl * tthreads, V.size, i, j);
+    if (live) {
+        size_t P = (size_t)V.size * V.size, p = (size_t)i * V.size + j;
+        D3 hit = dload(F.ghit + 3 * p);
+        D3 out = d3(0, 0, 0);
+        if (!(hit.x == -99999)) {
+            D3 nrm = dload(F.gnrm + 3 * p), Nt, Nb;
+            coord_system(nrm, Nt, Nb);
+            double r1;
+            D3 sm = sample_hemisphere(V.seed, V.view, (uint32_t)p, (uint32_t)(s0 + sl), r1);
+            D3 world = d3(sm.x * Nb.x + sm.y * nrm.x + sm.z * Nt.x,
+                          sm.x * Nb.y + sm.y * nrm.y + sm.z * Nt.y,
+                          sm.x * Nb.z + sm.y * nrm.z + sm.z * Nt.z);
+            RayD iray = make_ray(hit, world);
+            rc.n[RC_GI]++;
+            out = dscale(r1, cast_ray<MODEL, false>(S, iray, -1, nullptr, nullptr, rc));
+        }
+        dstore(F.contrib + ((size_t)sl * P + p) * 3, out);
+    }
+    flush_counts(rc, F.counters);
+}
+
+// indirect = indirect + r1 * L, in sample order (main.cpp:98).
+__global__ void k_gi_accumulate(FrameBuffers F, int size, int nb, int first_batch) {
+    size_t P = (size_t)size * size, p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    D3 acc = first_batch ? d3(0, 0, 0) : dload(F.gi_acc + 3 * p);
+    for (int s = 0; s < nb; s++) acc = dadd(acc, dload(F.contrib + ((size_t)s * P + p) * 3));
+    dstore(F.gi_acc + 3 * p, acc);
+}
+
+// mpnt + 2*mclr*GI/N (main.cpp:134, mainOMP.cpp:134), then the 8-bit BGR
+// quantisation of main.cpp:142-144 / mainOMP.cpp:194-196.
+__global__ void k_resolve(FrameBuffers F, int size, int gi, int nsamples) {
+    size_t P = (size_t)size * size, p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    D3 paint = dload(F.mpnt + 3 * p);
+    if (gi) {
+        D3 G = dload(F.gi_acc + 3 * p), clr = dload(F.gclr + 3 * p);
+        paint = dadd(paint, ddivs(dmul(dscale(2.0, clr), G), (double)nsamples));
+    }
+    dstore(F.rgb + 3 * p, paint);
+    int b = (int)(255.0 * paint.z), g = (int)(255.0 * paint.y), r = (int)(255.0 * paint.x);
+    F.bgr[3 * p] = (uint8_t)(b < 255 ? b : 255);
+    F.bgr[3 * p + 1] = (uint8_t)(g < 255 ? g : 255);
+    F.bgr[3 * p + 2] = (uint8_t)(r < 255 ? r : 255);
+}
+
+// search() on caller-supplied rays.
+__global__ void k_trace_exact(DevScene S, size_t n, const double *src, const double *dir, const double *tmin_in,
+                              int32_t *found, int32_t *tri, double *t, double *u, double *v) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    RayD ray = make_ray(dload(src + 3 * k), dload(dir + 3 * k));
+    HitD h; h.tmin = tmin_in[k]; h.tri = -1; h.u = 0; h.v = 0;
+    bool ok = search_ref(S, ray, h);
+    found[k] = ok; tri[k] = h.tri; t[k] = h.tmin; u[k] = h.u; v[k] = h.v;
+}
+
+__global__ void k_camera_rays(ViewParams V, double x, double y, double *dir) {
+    size_t P = (size_t)V.size * V.size, p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    int i = (int)(p / V.size), j = (int)(p % V.size);
+    RayD r = camera_ray(d3(V.eye[0], V.eye[1], V.eye[2]), V.zoom, V.sa, V.ca, V.size, i, j, x, y);
+    dstore(dir + 3 * p, r.dir);
+}
+
+__global__ void k_hemisphere(uint32_t seed, uint32_t view, uint32_t pixel, int n, double *out) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    double r1;
+    D3 v = sample_hemisphere(seed, view, pixel, (uint32_t)s, r1);
+    dstore(out + 3 * s, v);
+}
+
+// ---- host-side launchers ----------------------------------------------------------
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? PT_OK : PT_ERR_HIP)
+
+int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, hipStream_t s) {
+    int blocks = tile_threads(V.size) / 64;
+    if (V.model == PT_MODEL_MAIN)
+        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_MAIN>, dim3(blocks), dim3(64), 0, s, S, V, F);
+    else
+        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_OMP>, dim3(blocks), dim3(64), 0, s, S, V, F);
+    return LAUNCH_OK();
+}
+
+int exact_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, int s0, int nb, hipStream_t s) {
+    int tthreads = tile_threads(V.size);
+    unsigned blocks = (unsigned)(((size_t)tthreads * nb) / 64);
+    if (V.model == PT_MODEL_MAIN)
+        hipLaunchKernelGGL(k_gi_exact<PT_MODEL_MAIN>, dim3(blocks), dim3(64), 0, s, S, V, F, s0, tthreads);
+    else
+        hipLaunchKernelGGL(k_gi_exact<PT_MODEL_OMP>, dim3(blocks), dim3(64), 0, s, S, V, F, s0, tthreads);
+    return LAUNCH_OK();
+}
+
+int gi_accumulate(const FrameBuffers &F, int size, int nb, int first_batch, hipStream_t s) {
+    size_t P = (size_t)size * size;
+    hipLaunchKernelGGL(k_gi_accumulate, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, F, size, nb, first_batch);
+    return LAUNCH_OK();
+}
+
+int resolve_frame(const FrameBuffers &F, int size, int gi, int nsamples, hipStream_t s) {
+    size_t P = (size_t)size * size;
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, F, size, gi, nsamples);
+    return LAUNCH_OK();
+}
+
+int exact_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
+                int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s) {
+    hipLaunchKernelGGL(k_trace_exact, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, S, n, src, dir, tmin_in, found, tri, t, u, v);
+    return LAUNCH_OK();
+}
+
+int camera_rays(const ViewParams &V, double x, double y, double *dir, hipStream_t s) {
+    size_t P = (size_t)V.size * V.size;
+    hipLaunchKernelGGL(k_camera_rays, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, V, x, y, dir);
+    return LAUNCH_OK();
+}
+
+int hemisphere_samples(uint32_t seed, uint32_t view, uint32_t pixel, int n, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_hemisphere, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, view, pixel, n, out);
+    return LAUNCH_OK();
+}

@@ -1,0 +1,70 @@
+// Per-view parameters, frame buffers and the host-side launch functions that
+// the C ABI layer calls.  Kernels live in pt_exact.hip (fp64, built without
+// multiply-add contraction) and pt_fast.hip (fp32 GI wavefront path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_scene_dev.h"
+
+struct ViewParams {
+    double eye[3];
+    double zoom, sa, ca;      // sa, ca: sin / cos of the view angle (host libm)
+    int32_t size;             // image rows = cols
+    int32_t rb;               // 3x3 ray bundle
+    double off;               // bundle offset: 0.01 (main.cpp:116) or 0.1 (mainOMP.cpp:117)
+    uint32_t seed, view;
+    int32_t model;
+};
+
+struct FrameBuffers {
+    double *mpnt;             // 3 per pixel: direct pass result, main.cpp:31
+    double *gclr, *gnrm, *ghit;   // G-buffers, main.cpp:32-34
+    int32_t *rec_found, *rec_tri;
+    double *rec_t, *rec_u, *rec_v;
+    double *gi_acc;           // 3 per pixel: running `indirect` of globalIllumination
+    double *contrib;          // 3 per (sample of the batch, pixel): r1 * castRay(iray)
+    double *rgb;              // 3 per pixel, final linear colour
+    uint8_t *bgr;             // 3 per pixel
+    unsigned long long *counters;   // RC_N ray counters
+};
+
+
+// Queues and slots of the fp32 GI wavefront path (pt_fast.hip).
+struct FastBuffers {
+    float4 *rays_o;           // origin xyz, tmax
+    float4 *rays_d;           // direction xyz, weight r1 (cos theta)
+    uint32_t *ray_slot;       // contribution slot = sample_in_pass * P + pixel
+    int32_t *ray_skip;        // triangle the ray starts on (never reported as a hit)
+    float4 *hits;             // t, u, v, triangle index bits (-1: miss)
+    float4 *sp_pos;           // shading points (MAIN model): position xyz, triangle index bits
+    float4 *sp_nrm;           // normal xyz, slot bits
+    float4 *sp_base;          // r1 * 0.6 * txt * albedo / pi, unused
+    float4 *contrib;          // per slot: r1 * radiance of the sample ray
+    uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2..] reserved
+    size_t max_rays;
+};
+
+// One wave handles one 8x8 pixel tile, so that the rays of a wave stay close.
+static inline int tile_threads(int size) { int t = (size + 7) >> 3; return t * t * 64; }
+
+// ---- pt_exact.hip ----
+int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, hipStream_t s);
+int exact_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, int s0, int nb, hipStream_t s);
+int gi_accumulate(const FrameBuffers &F, int size, int nb, int first_batch, hipStream_t s);
+int resolve_frame(const FrameBuffers &F, int size, int gi, int nsamples, hipStream_t s);
+int exact_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
+                int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s);
+int camera_rays(const ViewParams &V, double x, double y, double *dir, hipStream_t s);
+int hemisphere_samples(uint32_t seed, uint32_t view, uint32_t pixel, int n, double *out, hipStream_t s);
+
+// ---- pt_fast.hip ----
+#define PT_FAST_RAYS_PER_PASS (16u << 20)
+typedef int (*PtAllocFn)(void *ctx, size_t bytes, void **out);
+int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *ctx);
+// All GI passes of one view: fills F.gi_acc.  trace_ms / launches: device time and
+// count of the closest-hit traversal launches; rays / shadow: query counts.
+int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers &Q, int nsamples, int batch,
+            hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow);
+int fast_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
+               int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s);

@@ -1,0 +1,51 @@
+// Device-resident scene: what the kernels see.  Filled by the upload code in
+// pt_abi.hip from a PtSceneDesc; all pointers are device memory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pathtracing_amd.h"
+
+// Traversal half of a kd node (fp64 path); the box is kept apart because it is
+// only read when a node's own triangle produces a candidate hit.
+struct NodeA {
+    double split;
+    int32_t axis;       // -1: leaf
+    int32_t left;       // right child = left + 1
+    int32_t first;      // first entry of the node's slice in the ref arrays
+    int32_t count;
+};
+
+// fp32 node of the GI fast path, 16 bytes, four to a 64-byte line.
+//   interior: split, left | axis << 30, first, count
+//   leaf    : split unused, 0xFFFFFFFF marker in `link`
+struct NodeF {
+    float split;
+    uint32_t link;      // interior: left child index (30 bits) | axis << 30; leaf: 0xFFFFFFFFu
+    uint32_t first;
+    uint32_t count;
+};
+
+struct DevScene {
+    // ---- fp64 reference-semantics path ----
+    const NodeA *nodeA;
+    const double *nodeBox;     // 6 per node: lo, hi
+    const double *refTri;      // 9 per ref: v0, v1 - v0, v2 - v0
+    const int32_t *refId;      // triangle index per ref
+    // ---- fp32 fast path ----
+    const NodeF *nodeF;
+    const float4 *refTriF;     // 3 float4 per ref: (v0, id bits), (e1, 0), (e2, 0)
+    // ---- shading data ----
+    const int32_t *tri_ni, *tri_ti, *tri_tm, *tri_reft, *tri_mesh, *tri_local;
+    const double *norm, *uv, *albedo;
+    const float *normF, *uvF;  // fp32 copies of the normal and uv pools (GI fast path)
+    const uint8_t *texels;
+    const int64_t *tex_off;
+    const int32_t *tex_rows, *tex_cols;
+    const PtLight *lights;
+    int32_t n_light, n_node, n_ref, n_tri;
+    double bg[3];
+    double root_lo[3], root_hi[3];
+};
+
+enum { RC_PRIMARY = 0, RC_SHADOW = 1, RC_MIRROR = 2, RC_GI = 3, RC_RETRACE = 4, RC_N = 8 };

@@ -1,0 +1,62 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SCENES = os.path.join(ROOT, "scenes")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def scene_path(name):
+    return os.path.join(SCENES, name + ".ptscene")
+
+
+@pytest.fixture(scope="session")
+def oracle_scenes():
+    """Oracle scenes (loaded + kd-tree built) keyed by name, built once per session."""
+    from oracle import ptoracle as po
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = po.OracleScene(scene_path(name))
+        return cache[name]
+    return get
+
+
+@pytest.fixture(scope="session")
+def host_scenes():
+    from pathtracing_amd import host
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            sc = host.HostScene.from_packed(scene_path(name))
+            sc.build_tree()
+            cache[name] = sc
+        return cache[name]
+    return get
+
+
+@pytest.fixture(scope="session")
+def gpu_scenes(host_scenes):
+    """Scenes uploaded to the GPU through the C ABI, keyed by name."""
+    from pathtracing_amd import device
+    device.init(0)
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = device.DeviceScene(host_scenes(name).desc())
+        return cache[name]
+    yield get
+    for s in cache.values():
+        s.close()

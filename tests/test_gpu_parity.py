@@ -1,0 +1,185 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.
+
+fp64 reference-semantics path: everything is compared bit for bit -- hit
+triangle ids, t, u, v, G-buffers, the linear image and the BGR8 frame.
+fp32 GI fast path: ids against the oracle's brute-force nearest hit on
+non-degenerate rays, t within 1e-5 relative, images by RMSE.
+"""
+import numpy as np
+import pytest
+
+from oracle import ptoracle as po
+from pathtracing_amd import device
+
+pytestmark = pytest.mark.gpu
+
+VIEW2 = dict(eye=[-350.0, 75.0, 350.0], angle=-0.7853981633974483 + 0.39269908169872414, zoom=1.0)
+
+
+def cam_of(host_scene):
+    c = host_scene.camera()
+    return dict(eye=c["eye"], angle=c["angle"], zoom=c["zoom"])
+
+
+def assert_same_frame(g, o, what):
+    for k in ("mesh", "tri"):
+        assert np.array_equal(g[k], o[k]), f"{what}: {k} differs on {(g[k] != o[k]).sum()} pixels"
+    for k in ("t", "u", "v", "gclr", "gnrm", "ghit", "rgb"):
+        same = g[k] == o[k]
+        assert same.all(), f"{what}: {k} differs on {(~same).sum()} values, max |d| = {np.abs(g[k] - o[k]).max()}"
+    assert np.array_equal(g["bgr"], o["bgr"]), f"{what}: BGR8 frame differs"
+
+
+def test_camera_rays_bit_exact(gpu_scenes, host_scenes):
+    gpu_scenes("cbox")
+    c = cam_of(host_scenes("car"))
+    for (x, y) in [(0.0, 0.0), (-0.01, 0.01), (0.1, -0.1)]:
+        g = device.camera_rays(c["eye"], c["angle"], c["zoom"], 512, x, y)
+        o = po.camera_rays(c["eye"], c["angle"], c["zoom"], 512, x, y)
+        assert np.array_equal(g, o)
+
+
+def test_hemisphere_samples_bit_exact(gpu_scenes):
+    gpu_scenes("cbox")
+    for (seed, view, pixel) in [(0x5EED, 0, 0), (1, 319, 262143), (0xFFFFFFFF, 7, 131072)]:
+        assert np.array_equal(device.hemisphere_samples(seed, view, pixel, 4096), po.hemisphere_samples(seed, view, pixel, 4096))
+
+
+@pytest.mark.parametrize("name", ["cbox", "car"])
+def test_direct_frame_bit_exact_main(gpu_scenes, oracle_scenes, host_scenes, name):
+    """config 1 (cbox direct, main.cpp model) and the same for car: every output bit for bit."""
+    c = cam_of(host_scenes(name))
+    g = gpu_scenes(name).render(**c, model=device.MODEL_MAIN)
+    o = oracle_scenes(name).render(**c, model=po.MODEL_MAIN, threads=16)
+    assert (g["mesh"] >= 0).sum() == 512 * 512
+    assert_same_frame(g, o, name + " direct")
+    oc = o["counts"]
+    st = g["stats"]
+    assert (st["primary"], st["shadow"], st["mirror"]) == (oc["primary"]["searches"], oc["shadow"]["searches"], oc["mirror"]["searches"])
+
+
+@pytest.mark.parametrize("name,model,rb", [("cbox", 0, False), ("cbox", 0, True), ("cbox", 1, False), ("cbox", 1, True),
+                                           ("car", 0, False), ("car", 1, False)])
+def test_gi_frame_bit_exact(gpu_scenes, oracle_scenes, host_scenes, name, model, rb):
+    """-gi (and -gi -rb) with the counter RNG: the fp64 path reproduces the oracle image exactly."""
+    c = cam_of(host_scenes(name))
+    g = gpu_scenes(name).render(**c, model=model, gi=True, rb=rb, gi_precision=device.GI_F64_EXACT, view=3)
+    o = oracle_scenes(name).render(**c, model=model, gi=True, rb=rb, rng=po.RNG_PHILOX, view=3, threads=16)
+    assert_same_frame(g, o, f"{name} model {model} rb {rb}")
+    oc, st = o["counts"], g["stats"]
+    assert st["gi"] == oc["gi"]["searches"] and st["primary"] == oc["primary"]["searches"]
+    assert st["shadow"] == oc["shadow"]["searches"] and st["omp_retrace"] == oc["omp_retrace"]["searches"]
+
+
+def test_second_view_and_small_sizes(gpu_scenes, oracle_scenes):
+    g = gpu_scenes("car").render(**VIEW2, model=device.MODEL_MAIN, gi=True, spp=2, size=96)
+    o = oracle_scenes("car").render(**VIEW2, model=po.MODEL_MAIN, gi=True, spp=2, size=96, threads=16)
+    assert_same_frame(g, o, "car 96x96")
+    for size in (1, 7, 8, 65):       # ragged tiles
+        g = gpu_scenes("cbox").render(eye=[0, 75, 80], angle=-1.2, zoom=1.0, size=size, gi=True, spp=3)
+        o = oracle_scenes("cbox").render(eye=[0, 75, 80], angle=-1.2, zoom=1.0, size=size, gi=True, spp=3)
+        assert_same_frame(g, o, f"cbox {size}x{size}")
+
+
+def test_view_with_misses(gpu_scenes, oracle_scenes):
+    """Looking out of the open side of the box: background pixels, G-buffer miss marker."""
+    v = dict(eye=[0.0, 75.0, 400.0], angle=np.pi / 2, zoom=1.0)
+    g = gpu_scenes("cbox").render(**v, gi=True, size=128)
+    o = oracle_scenes("cbox").render(**v, gi=True, size=128)
+    assert (o["mesh"] < 0).sum() > 1000
+    assert_same_frame(g, o, "cbox misses")
+
+
+def test_many_samples_in_batches(gpu_scenes, oracle_scenes):
+    """More samples than one pass holds: ordered accumulation across passes."""
+    v = dict(eye=[0.0, 75.0, 80.0], angle=-np.pi / 2, zoom=1.0)
+    g = gpu_scenes("cbox").render(**v, gi=True, spp=37, size=64, model=device.MODEL_OMP)
+    o = oracle_scenes("cbox").render(**v, gi=True, spp=37, size=64, model=po.MODEL_OMP, threads=16)
+    assert_same_frame(g, o, "cbox 37 spp")
+
+
+def random_rays(n, seed, box):
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array(box[:3]), np.array(box[3:])
+    src = lo + (hi - lo) * (0.1 + 0.8 * rng.random((n, 3)))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[: n // 50, 0] = 0.0            # axis-parallel directions: zero components, infinite reciprocals
+    d[n // 50: n // 25, 1] = 0.0
+    return src, d
+
+
+@pytest.mark.parametrize("name", ["cbox", "car"])
+def test_trace_random_rays_bit_exact(gpu_scenes, oracle_scenes, name):
+    """pt_trace mode 0 == search() of the reference on incoherent rays, closest-hit and bounded."""
+    s = oracle_scenes(name)
+    src, d = random_rays(20000, 7, s.root_box())
+    for tmin in (np.full(len(src), device.FLT_MAX), np.random.default_rng(3).random(len(src)) * 200.0):
+        g = gpu_scenes(name).trace(src, d, tmin, mode=0)
+        o = s.trace(src, d, tmin, mode=0)
+        for k in ("found", "mesh", "tri", "t", "u", "v"):
+            assert np.array_equal(g[k], o[k]), k
+    assert gpu_scenes(name).trace(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0))["found"].size == 0
+
+
+@pytest.mark.parametrize("name", ["cbox", "car"])
+def test_fast_trace_against_brute_force(gpu_scenes, oracle_scenes, name):
+    """pt_trace mode 1 (fp32 kd traversal, the GI fast path) finds the true nearest hit:
+    same triangle as an fp64 brute force wherever the two nearest candidates are not
+    within fp32 noise of each other, t within 1e-5 relative."""
+    s = oracle_scenes(name)
+    src, d = random_rays(20000, 11, s.root_box())
+    tmin = np.full(len(src), device.FLT_MAX)
+    g = gpu_scenes(name).trace(src, d, tmin, mode=1)
+    o = s.trace(src, d, tmin, mode=1)
+    both = (g["found"] == 1) & (o["found"] == 1)
+    assert (g["found"] != o["found"]).mean() < 2e-3
+    same = both & (g["mesh"] == o["mesh"]) & (g["tri"] == o["tri"])
+    assert same.sum() / both.sum() > 0.995
+    rel = np.abs(g["t"][same] - o["t"][same]) / o["t"][same]
+    assert np.quantile(rel, 0.999) < 1e-5, rel.max()
+
+
+@pytest.mark.parametrize("name,model", [("cbox", 0), ("cbox", 1), ("car", 0), ("car", 1)])
+def test_fast_gi_image_close_to_exact(gpu_scenes, host_scenes, name, model):
+    """fp32 GI wavefront path vs fp64 path at equal spp and equal sample directions:
+    RMSE of the linear image below 2e-3 (measured: a few 1e-4), primary outputs identical."""
+    c = cam_of(host_scenes(name))
+    sc = gpu_scenes(name)
+    a = sc.render(**c, model=model, gi=True, spp=8, gi_precision=device.GI_F64_EXACT)
+    b = sc.render(**c, model=model, gi=True, spp=8, gi_precision=device.GI_F32_FAST)
+    for k in ("mesh", "tri", "t", "gclr", "gnrm", "ghit"):
+        assert np.array_equal(a[k], b[k])
+    rmse = float(np.sqrt(np.mean((a["rgb"] - b["rgb"]) ** 2)))
+    assert rmse < 2e-3, rmse
+    assert abs(a["rgb"].mean() - b["rgb"].mean()) < 2e-4
+    assert a["stats"]["gi"] == b["stats"]["gi"]
+    # bit-reproducible run to run (contribution slots, no float atomics)
+    b2 = sc.render(**c, model=model, gi=True, spp=8, gi_precision=device.GI_F32_FAST)
+    assert np.array_equal(b["rgb"], b2["rgb"])
+
+
+def test_blob_upload_and_multi_view(gpu_scenes, host_scenes):
+    hs = host_scenes("cbox")
+    blob = device.scene_blob(hs.desc())
+    sc2 = device.DeviceScene(blob=blob)
+    c = cam_of(hs)
+    a = gpu_scenes("cbox").render(**c, gi=True, spp=2, size=128)
+    b = sc2.render(**c, gi=True, spp=2, size=128)
+    assert np.array_equal(a["rgb"], b["rgb"])
+    cams = [device.make_camera([0, 75, 80 - 10 * k], -np.pi / 2 + 0.2 * k, 1.0) for k in range(3)]
+    frames, st = sc2.render_views(cams, view0=5, view_stride=2, gi=True, spp=2, size=128)
+    for k, cam in enumerate(cams):
+        one = sc2.render(list(cam.eye), cam.angle, cam.zoom, gi=True, spp=2, size=128, view=5 + 2 * k, aov=False)
+        assert np.array_equal(frames[k], one["bgr"])
+    sc2.close()
+
+
+def test_errors(gpu_scenes, host_scenes):
+    sc = gpu_scenes("cbox")
+    with pytest.raises(device.DeviceError):
+        sc.render([0, 0, 0], 0.0, 1.0, model=7)
+    with pytest.raises(device.DeviceError):
+        sc.render([0, 0, 0], 0.0, 1.0, size=100000)
+    with pytest.raises(device.DeviceError):
+        device.DeviceScene(blob=np.zeros(64, np.uint8))
