@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path: views of a -gi job through the HIP path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one 512x512 view rendered per GPU (primary + mirror + shadow rays in
+fp64, GI sample rays through the fp32 wavefront path), the frame left in device
+memory and gathered to rank 0.  With N > 1 (one process per GPU, launched by
+torch.distributed.run) rank 0 reads the scene, builds the kd-tree and hands
+the packed scene to the other ranks with one RCCL broadcast; views are dealt
+round-robin, view v -> rank v % N, and no other collective touches the data
+path.  Rank 0 prints one JSON line.
+
+value    = rays of all classes traced by all ranks / wall time of the K steps
+roofline = the GI closest-hit kernel (the dominant kernel): algorithmic bytes
+           per launch / mean launch duration (HIP events on the kernel's stream)
+cpu_baseline = the CPU oracle (a port of the reference's render path) timed on
+           a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (packed scene or generator, path file, label)
+    "car": ("scenes/car.ptscene", "scenes/paths/carpath.txt", "car -gi (10 264 triangles), views of scenes/paths/carpath.txt"),
+    "cbox": ("scenes/cbox.ptscene", "scenes/paths/cboxpath.txt", "cbox -gi (2 190 triangles), views of scenes/paths/cboxpath.txt"),
+    "atrium": (None, None, "atrium-262k -gi: procedural stand-in (262 267 triangles, seed 12345) for the sponza mesh, "
+                           "which is not available; not Crytek Sponza"),
+}
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, spec
+
+
+def load_host_scene(name):
+    from pathtracing_amd import host
+    packed, path_file, _ = WORKLOADS[name]
+    if packed is None:
+        hs = host.HostScene.atrium(262267, 12345)
+    else:
+        hs = host.HostScene.from_packed(os.path.join(ROOT, packed))
+    st = hs.build_tree()
+    cam = hs.camera()
+    if path_file is not None:
+        views = list(host.views_from_path(os.path.join(ROOT, path_file), cam["zoom"]))
+    else:
+        views = atrium_views(cam)
+    return hs, st, views
+
+
+def atrium_views(cam):
+    """20 positions x 16 yaw angles along the nave, the shape of the reference's path files."""
+    from pathtracing_amd import host
+    views = []
+    for k in range(20):
+        x = -1500.0 + 150.0 * k
+        for j in range(16):
+            v = host.PtCamera((C.c_double * 3)(x, 300.0, -50.0 + 20.0 * ((k % 5) - 2)), cam["angle"] + np.pi / 8 * j, cam["zoom"])
+            views.append(v)
+    return views
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("PT_BENCH_WORKLOAD", "atrium"), choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--model", default="omp", choices=["main", "omp"])
+    ap.add_argument("--rb", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=8, help="image rows of the CPU baseline sample")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one process per GPU)")
+        a.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from pathtracing_amd import device
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    device.init(local_rank)
+    model = device.MODEL_OMP if a.model == "omp" else device.MODEL_MAIN
+
+    # ---- scene: read + kd build on rank 0, RCCL broadcast of the packed blob ----
+    t_scene = time.time()
+    hs = st = None
+    if rank == 0:
+        hs, st, views = load_host_scene(a.workload)
+        blob = device.scene_blob(hs.desc())
+        cams = np.array([[*v.eye, v.angle, v.zoom] for v in views])
+    if world > 1:
+        meta = torch.zeros(2, dtype=torch.int64, device=dev)
+        if rank == 0:
+            meta[0], meta[1] = blob.size, len(cams)
+        dist.broadcast(meta, 0)
+        d_blob = torch.empty(int(meta[0]), dtype=torch.uint8, device=dev)
+        d_cams = torch.empty((int(meta[1]), 5), dtype=torch.float64, device=dev)
+        if rank == 0:
+            d_blob.copy_(torch.from_numpy(blob))
+            d_cams.copy_(torch.from_numpy(cams))
+        dist.broadcast(d_blob, 0)           # the scene + kd-tree travel over xGMI once
+        dist.broadcast(d_cams, 0)
+        blob = d_blob.cpu().numpy()
+        cams = d_cams.cpu().numpy()
+    ds = device.DeviceScene(blob=blob)
+    scene_seconds = time.time() - t_scene
+    views = [device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])) for c in cams]
+    nviews = len(views)
+
+    size = 512
+    opt = dict(gi=True, rb=a.rb, model=model, spp=a.spp, gi_precision=device.GI_F32_FAST, size=size)
+    frame = torch.empty(size * size * 3, dtype=torch.uint8, device=dev)
+    gathered = [torch.empty_like(frame) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step(i, stats):
+        v = (i * world + rank) % nviews
+        ds.render_to_device(views[v], frame.data_ptr(), stats=stats, view=v, **opt)
+        if world > 1:
+            dist.gather(frame, gathered, dst=0)   # finished frames go to rank 0
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    warm = device.PtStats()
+    for i in range(a.warmup):
+        step(i, warm)
+    stats = device.PtStats()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i, stats)
+    sync()
+    dt = time.perf_counter() - t0
+
+    rays_local = stats.primary + stats.shadow + stats.mirror + stats.gi
+    agg = torch.tensor([dt, float(rays_local), float(stats.gi)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = agg[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg[1:], op=dist.ReduceOp.SUM)
+        agg[0] = tmax[0]
+    dt_max, rays_total, gi_total = (float(x) for x in agg.cpu())
+
+    if rank == 0:
+        # ---- algorithmic bytes per ray of the dominant kernel: a counting run (untimed) ----
+        cst = device.PtStats()
+        ds.render_to_device(views[a.warmup % nviews], frame.data_ptr(), stats=cst, view=a.warmup % nviews,
+                            flags=device.FLAG_COUNT_WORK, **opt)
+        n_node = cst.gi_nodes_visited / max(cst.gi, 1)
+        n_tri = cst.gi_tris_tested / max(cst.gi, 1)
+        # per closest-hit ray: 32 B ray in + 16 B hit out + 16 B per node visited + (4 + 36) B per triangle tested
+        bytes_per_ray = 32 + 16 + 16 * n_node + 40 * n_tri
+        launches = max(stats.gi_trace_launches, 1)
+        ms_launch = stats.ms_gi_trace / launches
+        rays_launch = stats.gi / launches
+        achieved = bytes_per_ray * rays_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(n_node, 2),
+                    "tris_per_ray": round(n_tri, 2), "rays_per_launch": int(rays_launch),
+                    "ms_per_launch": round(ms_launch, 4),
+                    "kernel_mrays_per_s": round(rays_launch / (ms_launch * 1e-3) / 1e6, 1) if ms_launch > 0 else 0.0}
+
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import ptoracle as po
+            packed = WORKLOADS[a.workload][0]
+            tmp = None
+            if packed is None:
+                tmp = os.path.join("/tmp", f"bench_{a.workload}_{os.getpid()}.ptscene")
+                hs.save_packed(tmp)
+                packed_path = tmp
+            else:
+                packed_path = os.path.join(ROOT, packed)
+            orc = po.OracleScene(packed_path)
+            if tmp:
+                os.remove(tmp)
+            cores = min(16, os.cpu_count() or 1, a.cpu_rows)
+            v0 = views[a.warmup % nviews]
+            r = orc.render(eye=list(v0.eye), angle=v0.angle, zoom=v0.zoom, model=po.MODEL_OMP if a.model == "omp" else po.MODEL_MAIN,
+                           gi=True, rb=a.rb, spp=a.spp, rng=po.RNG_PHILOX, view=a.warmup % nviews, size=size,
+                           row0=size // (2 * a.cpu_rows), row_step=size // a.cpu_rows, nrows_limit=a.cpu_rows,
+                           threads=cores, aov=False)
+            crays = sum(v["searches"] for k, v in r["counts"].items() if k != "omp_retrace")
+            cpu = {"value": round(crays / r["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "sample": f"{a.cpu_rows} of 512 image rows (every {size // a.cpu_rows}th) of one view at the same spp, "
+                             f"{crays} rays in {r['seconds']:.1f} s"}
+
+        out = {
+            "metric": "Mrays/s (all ray classes of -gi views; GI sample rays dominate)",
+            "value": round(rays_total / dt_max / 1e6, 1),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt_max / a.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (GI sample rays) + f64 (primary, mirror, their shadow rays)",
+            "data": "synthetic" if a.workload == "atrium" else "reference scene file, packed",
+            "config": {"workload": WORKLOADS[a.workload][2], "spp": a.spp, "model": a.model, "rb": bool(a.rb),
+                       "image": "512x512", "views_per_step": world, "parallelism": f"views round-robin over {world} GPU(s)",
+                       "triangles": st["triangles"], "kd_refs": st["optimized"], "kd_nodes": st["nodes"]},
+            "views_per_s": round(a.steps * world / dt_max, 3),
+            "gi_mrays_per_s": round(gi_total / dt_max / 1e6, 1),
+            "scene_setup_s": round(scene_seconds, 2),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    ds.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,7 +91,12 @@ typedef struct PtOptions {
     uint32_t seed;            /* key of the counter RNG */
     uint32_t view;            /* second key word: index of the view in a multi-view job */
     int32_t size;             /* image rows = cols; 0 = 512 (main.cpp:14) */
+    uint32_t flags;           /* PT_FLAG_* */
 } PtOptions;
+
+/* Count the nodes visited and triangles tested by the GI closest-hit kernel
+   (PT_GI_F32_FAST only).  Slower; used to price the kernel's algorithmic bytes. */
+#define PT_FLAG_COUNT_WORK 1u
 
 /* Optional per-pixel outputs of pt_render_view (any pointer may be NULL).
    The primary record is that of the ray whose G-buffer the GI pass uses:
@@ -110,6 +115,7 @@ typedef struct PtStats {
     double ms_total;          /* wall time of the call                     */
     double ms_gi_trace;       /* device time of the GI closest-hit kernels */
     uint64_t gi_trace_launches;
+    uint64_t gi_nodes_visited, gi_tris_tested;   /* only with PT_FLAG_COUNT_WORK */
 } PtStats;
 
 typedef struct PtScene PtScene;

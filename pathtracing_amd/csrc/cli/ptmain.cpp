@@ -1,0 +1,130 @@
+// ptmain -- command-line front end with the reference's surface:
+//
+//     ptmain [scene] [-gi] [-rb] [-rm]
+//
+// (main.cpp:191-206, mainOMP.cpp:328-354).  Scene input is scenes/<scene>/ in the
+// reference's text format, or scenes/<scene>.ptscene when only the packed file
+// exists.  The host side (reader, kd build, view list) runs here; rendering goes
+// through the C ABI of libptamd.so.  Frames are written as image files instead
+// of being shown in a window.
+//
+// Extensions, all optional: --model main|omp (default: main, or omp with -rm as
+// that flag belongs to mainOMP.cpp), --spp N, --exact-gi (fp64 GI), --out DIR,
+// --size N, --views N (limit of -rm), --device K, --keys "wasdlr..." (camera
+// steps of simulate(), one frame per key).
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pathtracing_amd.h"
+#include "pathtracing_host.h"
+
+static bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+static int die(const char *what, const char *msg) {
+    std::fprintf(stderr, "ptmain: %s: %s\n", what, msg);
+    return 1;
+}
+
+int main(int argc, char **argv) {
+    bool gi = false, rb = false, rm = false, exact_gi = false;
+    std::string scene, model_s, out = ".", keys;
+    int spp = 0, size = 0, max_views = -1, dev = 0;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto val = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) { std::fprintf(stderr, "ptmain: %s needs a value\n", name); std::exit(2); }
+            return argv[++i];
+        };
+        if (a == "-gi") gi = true;
+        else if (a == "-rb") rb = true;
+        else if (a == "-rm") rm = true;
+        else if (a == "-pp") { std::fprintf(stderr, "ptmain: -pp (Keras post-processing) is not part of this build\n"); return 2; }
+        else if (a == "--model") model_s = val("--model");
+        else if (a == "--spp") spp = std::atoi(val("--spp"));
+        else if (a == "--size") size = std::atoi(val("--size"));
+        else if (a == "--views") max_views = std::atoi(val("--views"));
+        else if (a == "--device") dev = std::atoi(val("--device"));
+        else if (a == "--out") out = val("--out");
+        else if (a == "--keys") keys = val("--keys");
+        else if (a == "--exact-gi") exact_gi = true;
+        else if (!a.empty() && a[0] != '-') scene = a;
+        else { std::fprintf(stderr, "ptmain: unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (scene.empty()) { std::fprintf(stderr, "usage: ptmain [scene] [-gi] [-rb] [-rm]\n"); return 2; }
+    int model = rm ? PT_MODEL_OMP : PT_MODEL_MAIN;
+    if (model_s == "main") model = PT_MODEL_MAIN;
+    else if (model_s == "omp") model = PT_MODEL_OMP;
+    else if (!model_s.empty()) { std::fprintf(stderr, "ptmain: --model must be main or omp\n"); return 2; }
+
+    PthScene *hs = nullptr;
+    std::string dir = "scenes/" + scene, packed = dir + ".ptscene";
+    int rc = exists(dir + "/master.txt") ? pth_scene_load_dir(dir.c_str(), nullptr, &hs) : pth_scene_load_packed(packed.c_str(), &hs);
+    if (rc) return die("scene", pth_last_error());
+    PthTreeStats ts;
+    if (pth_scene_build_tree(hs, &ts)) return die("kd build", pth_last_error());
+    std::printf("Real Triangles: %lld; Naive: %lld; Optimized: %lld\n", (long long)ts.triangles, (long long)ts.naive,
+                (long long)ts.optimized);
+    PtSceneDesc desc;
+    if (pth_scene_desc(hs, &desc)) return die("scene", pth_last_error());
+    if (pt_init(dev)) return die("pt_init", pt_last_error());
+    PtScene *ds = nullptr;
+    if (pt_scene_upload(&desc, &ds)) return die("pt_scene_upload", pt_last_error());
+
+    double cam7[7];
+    pth_scene_camera(hs, cam7);
+    PtOptions opt{};
+    opt.struct_size = sizeof opt;
+    opt.gi = gi; opt.rb = rb; opt.model = model; opt.spp = spp; opt.size = size;
+    opt.gi_precision = exact_gi ? PT_GI_F64_EXACT : PT_GI_F32_FAST;
+    opt.seed = 0x5EED;
+    const int n = size ? size : 512;
+    std::vector<uint8_t> frame((size_t)n * n * 3);
+
+    auto render_one = [&](const PtCamera &cam, uint32_t view, const std::string &file) -> int {
+        opt.view = view;
+        PtStats st{};
+        auto t0 = std::chrono::high_resolution_clock::now();
+        if (pt_render_view(ds, &cam, &opt, frame.data(), nullptr, &st)) return die("pt_render_view", pt_last_error());
+        std::chrono::duration<double> el = std::chrono::high_resolution_clock::now() - t0;
+        std::printf("Elapsed time: %g s\n", el.count());      // main.cpp:158, mainOMP.cpp:241
+        unsigned long long rays = st.primary + st.shadow + st.mirror + st.gi;
+        std::printf("  rays: primary %llu shadow %llu mirror %llu gi %llu  (%.1f Mrays/s) -> %s\n",
+                    (unsigned long long)st.primary, (unsigned long long)st.shadow, (unsigned long long)st.mirror,
+                    (unsigned long long)st.gi, rays / el.count() * 1e-6, file.c_str());
+        if (pth_write_ppm(file.c_str(), frame.data(), n, n)) return die("write", pth_last_error());
+        return 0;
+    };
+
+    if (rm) {                                                   // renderMultiple, mainOMP.cpp:225-247
+        std::string pf = "scenes/paths/" + scene + "path.txt";
+        size_t total = 0;
+        if (pth_views_from_path(pf.c_str(), cam7[6], nullptr, 0, &total)) return die("path file", pth_last_error());
+        std::vector<PtCamera> cams(total);
+        if (pth_views_from_path(pf.c_str(), cam7[6], cams.data(), total, &total)) return die("path file", pth_last_error());
+        if (max_views >= 0 && (size_t)max_views < total) total = (size_t)max_views;
+        for (size_t v = 0; v < total; v++) {
+            char name[64];
+            std::snprintf(name, sizeof name, "/%s%zu.ppm", scene.c_str(), v);
+            if (render_one(cams[v], (uint32_t)v, out + name)) return 1;
+        }
+    } else {                                                    // simulate(), main.cpp:152-189
+        PtCamera cam{{cam7[0], cam7[1], cam7[2]}, cam7[5], cam7[6]};
+        if (render_one(cam, 0, out + "/" + scene + ".ppm")) return 1;
+        for (size_t k = 0; k < keys.size(); k++) {
+            if (pth_camera_step(cam.eye, &cam.angle, cam7[3], cam7[4], keys[k])) return die("--keys", pth_last_error());
+            char name[64];
+            std::snprintf(name, sizeof name, "/%s_step%zu.ppm", scene.c_str(), k + 1);
+            if (render_one(cam, 0, out + name)) return 1;
+        }
+    }
+    pt_scene_free(ds);
+    pth_scene_free(hs);
+    pt_shutdown();
+    return 0;
+}

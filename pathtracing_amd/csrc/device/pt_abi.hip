@@ -324,10 +324,12 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     HIPCHK(hipMemsetAsync(F.counters, 0, RC_N * sizeof(unsigned long long), s));
     if (exact_primary(sc->S, V, F, s)) return fail(PT_ERR_HIP, "primary pass launch failed");
     *gi_ms = 0; *gi_launches = 0;
-    uint64_t fast_rays = 0, fast_shadow = 0;
+    uint64_t fast_rays = 0, fast_shadow = 0, fast_work[2] = {0, 0};
+    const bool count_work = fast && (o->flags & PT_FLAG_COUNT_WORK);
     if (o->gi) {
         if (fast) {
-            rc = fast_gi(sc->S, V, F, sc->ws.Q, N, batch, s, sc->ev0, sc->ev1, gi_ms, gi_launches, &fast_rays, &fast_shadow);
+            rc = fast_gi(sc->S, V, F, sc->ws.Q, N, batch, s, sc->ev0, sc->ev1, gi_ms, gi_launches, &fast_rays, &fast_shadow,
+                         count_work ? fast_work : nullptr);
             if (rc) return fail(rc, std::string("GI wavefront pass failed: ") + hipGetErrorString(hipGetLastError()));
         } else {
             for (int s0 = 0; s0 < N; s0 += batch) {
@@ -351,6 +353,7 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
         st->primary += c[RC_PRIMARY]; st->shadow += c[RC_SHADOW]; st->mirror += c[RC_MIRROR];
         st->gi += c[RC_GI] + fast_rays; st->shadow += fast_shadow; st->omp_retrace += c[RC_RETRACE];
         st->ms_gi_trace += *gi_ms; st->gi_trace_launches += *gi_launches;
+        st->gi_nodes_visited += fast_work[0]; st->gi_tris_tested += fast_work[1];
     }
     return PT_OK;
 }

@@ -35,9 +35,13 @@ __device__ __forceinline__ float sel3(uint32_t a, float x, float y, float z) { r
 // where the previous leaf's segment ended.  It is a ring of FS_SLOTS entries per
 // lane in LDS; when it overflows the oldest entry is dropped and, once the ring
 // runs empty, traversal restarts from the root at the current segment start.
-template <bool ANY>
+//
+// COUNT adds two per-lane counters (nodes visited, triangles tested) for the
+// work census that prices the kernel's algorithmic bytes; the timed build has
+// COUNT = false.
+template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool trace_f32(const DevScene &S, float ox, float oy, float oz, float dx, float dy, float dz,
-                                          float tmax, int skip, uint2 *stk, HitF &h) {
+                                          float tmax, int skip, uint2 *stk, HitF &h, uint32_t *work = nullptr) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     float ent, ext;
     {
@@ -59,22 +63,30 @@ __device__ __forceinline__ bool trace_f32(const DevScene &S, float ox, float oy,
     for (;;) {
         NodeF n = S.nodeF[curr];
         for (;;) {
-            const float4 *tp = S.refTriF + (size_t)n.first * 3;
-            for (uint32_t i = 0; i < n.count; i++, tp += 3) {
+            if (COUNT) { work[0]++; work[1] += n.count; }
+            if (n.count) {
+                // The next triangle's 48 bytes are requested before the current one is
+                // tested, so that two loads per lane are in flight along the list.
+                const float4 *tp = S.refTriF + (size_t)n.first * 3;
                 float4 A = tp[0], B = tp[1], C = tp[2];
-                float px = dy * C.z - dz * C.y, py = dz * C.x - dx * C.z, pz = dx * C.y - dy * C.x;
-                float det = px * B.x + py * B.y + pz * B.z;
-                float inv = 1.0f / det;
-                float tx = ox - A.x, ty = oy - A.y, tz = oz - A.z;
-                float u = (px * tx + py * ty + pz * tz) * inv;
-                float qx = ty * B.z - tz * B.y, qy = tz * B.x - tx * B.z, qz = tx * B.y - ty * B.x;
-                float v = (qx * dx + qy * dy + qz * dz) * inv;
-                float t = (qx * C.x + qy * C.y + qz * C.z) * inv;
-                int id = __float_as_int(A.w);
-                if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > 0.0f && t < tmin && id != skip) {
-                    tmin = t; h.t = t; h.u = u; h.v = v; h.tri = id;
-                    found = true;
-                    if (ANY) return true;
+                for (uint32_t i = 0; i < n.count; i++) {
+                    tp += (i + 1 < n.count) ? 3 : 0;
+                    float4 An = tp[0], Bn = tp[1], Cn = tp[2];
+                    float px = dy * C.z - dz * C.y, py = dz * C.x - dx * C.z, pz = dx * C.y - dy * C.x;
+                    float det = px * B.x + py * B.y + pz * B.z;
+                    float inv = 1.0f / det;
+                    float tx = ox - A.x, ty = oy - A.y, tz = oz - A.z;
+                    float u = (px * tx + py * ty + pz * tz) * inv;
+                    float qx = ty * B.z - tz * B.y, qy = tz * B.x - tx * B.z, qz = tx * B.y - ty * B.x;
+                    float v = (qx * dx + qy * dy + qz * dz) * inv;
+                    float t = (qx * C.x + qy * C.y + qz * C.z) * inv;
+                    int id = __float_as_int(A.w);
+                    if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > 0.0f && t < tmin && id != skip) {
+                        tmin = t; h.t = t; h.u = u; h.v = v; h.tri = id;
+                        found = true;
+                        if (ANY) return true;
+                    }
+                    A = An; B = Bn; C = Cn;
                 }
             }
             if (n.link == 0xFFFFFFFFu) break;
@@ -178,14 +190,151 @@ __global__ void __launch_bounds__(64) k_gi_gen(ViewParams V, FrameBuffers F, Fas
 }
 
 // ---- stage 2: closest hit -------------------------------------------------------
+// Persistent waves.  Rays differ a lot in length (a ray that threads a cluster
+// of fat leaves costs tens of times the mean), so a wave that owned 64 fixed
+// rays would idle most of its lanes most of the time.  Instead every lane runs
+// a small state machine and advances by ONE unit per loop turn -- one triangle
+// test if its current node still has untested triangles, else one node step
+// (descend / pop / restart) -- and lanes whose ray is finished draw new rays
+// from the queue head (one atomicAdd per wave, when at least PT_REFILL_MIN
+// lanes are idle).  A wave leaves when the queue is drained and all its lanes
+// are done, so the grid always drains.
+#define PT_REFILL_MIN 16
+#define PT_TRACE_WAVES (256 * 32)     // enough waves to fill every CU; surplus waves find the queue empty
+
+template <bool COUNT>
 __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q) {
     __shared__ uint2 stack[FS_SLOTS * 64];
-    uint32_t r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= Q.counts[0]) return;
-    float4 o = Q.rays_o[r], d = Q.rays_d[r];
-    HitF h; h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
-    trace_f32<false>(S, o.x, o.y, o.z, d.x, d.y, d.z, o.w, Q.ray_skip[r], stack + (threadIdx.x & 63), h);
-    Q.hits[r] = make_float4(h.t, h.u, h.v, __int_as_float(h.tri));
+    const uint32_t lane = threadIdx.x & 63;
+    uint2 *stk = stack + lane;
+    const uint32_t n_rays = Q.counts[0];
+    const float lx = (float)S.root_lo[0], ly = (float)S.root_lo[1], lz = (float)S.root_lo[2];
+    const float hx = (float)S.root_hi[0], hy = (float)S.root_hi[1], hz = (float)S.root_hi[2];
+
+    bool active = false, more = true;
+    uint32_t r = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0;
+    float tmin = 0, ent = 0, ext = 0, root_ext = 0, hu = 0, hv = 0;
+    int htri = -1, skip = -1;
+    uint32_t curr = 0, top = 0, cnt = 0, ti = 0, te = 0, steps = 0;
+    bool dropped = false;
+    NodeF n; n.split = 0; n.link = 0xFFFFFFFFu; n.first = 0; n.count = 0;
+    uint32_t w_nodes = 0, w_tris = 0;
+
+    for (;;) {
+        unsigned long long idle = __ballot(!active);
+        if (more && __popcll(idle) >= PT_REFILL_MIN) {
+            uint32_t want = (uint32_t)__popcll(idle), base = 0;
+            if (lane == 0) base = atomicAdd(&Q.counts[3], want);
+            base = __shfl(base, 0, 64);
+            if (base + want >= n_rays) more = false;
+            if (!active) {
+                uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (mine < n_rays) {
+                    r = mine;
+                    float4 o = Q.rays_o[r], d = Q.rays_d[r];
+                    skip = Q.ray_skip[r];
+                    ox = o.x; oy = o.y; oz = o.z; dx = d.x; dy = d.y; dz = d.z;
+                    ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+                    float a0 = (lx - ox) * ix, a1 = (hx - ox) * ix;
+                    float b0 = (ly - oy) * iy, b1 = (hy - oy) * iy;
+                    float c0 = (lz - oz) * iz, c1 = (hz - oz) * iz;
+                    ent = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+                    ext = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), o.w));
+                    tmin = o.w; htri = -1; hu = 0; hv = 0;
+                    if (ent <= ext) {
+                        active = true;
+                        root_ext = ext;
+                        curr = 0; top = 0; cnt = 0; dropped = false; steps = 0;
+                        n = S.nodeF[0];
+                        ti = n.first; te = n.first + n.count;
+                        if (COUNT) { w_nodes++; w_tris += n.count; }
+                    } else {
+                        Q.hits[r] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+                    }
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (!more) break;
+            continue;
+        }
+        if (active) {
+            if (ti < te) {
+                // ---- one triangle of the current node ----
+                const float4 *tp = S.refTriF + (size_t)ti * 3;
+                float4 A = tp[0], B = tp[1], C = tp[2];
+                ti++;
+                float px = dy * C.z - dz * C.y, py = dz * C.x - dx * C.z, pz = dx * C.y - dy * C.x;
+                float det = px * B.x + py * B.y + pz * B.z;
+                float inv = 1.0f / det;
+                float tx = ox - A.x, ty = oy - A.y, tz = oz - A.z;
+                float u = (px * tx + py * ty + pz * tz) * inv;
+                float qx = ty * B.z - tz * B.y, qy = tz * B.x - tx * B.z, qz = tx * B.y - ty * B.x;
+                float v = (qx * dx + qy * dy + qz * dz) * inv;
+                float t = (qx * C.x + qy * C.y + qz * C.z) * inv;
+                int id = __float_as_int(A.w);
+                if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > 0.0f && t < tmin && id != skip) {
+                    tmin = t; hu = u; hv = v; htri = id;
+                }
+            } else {
+                // ---- one node step ----
+                bool done = false;
+                if (n.link == 0xFFFFFFFFu) {
+                    ent = ext;                      // the next segment starts where this leaf's ended
+                    if (ent >= tmin) {
+                        done = true;
+                    } else if (cnt > 0) {
+                        top = (top - 1) & (FS_SLOTS - 1);
+                        cnt--;
+                        uint2 e = stk[top * 64];
+                        curr = e.x; ext = __uint_as_float(e.y);
+                    } else if (dropped) {
+                        dropped = false;
+                        curr = 0; ext = root_ext;
+                    } else {
+                        done = true;
+                    }
+                } else {
+                    uint32_t axis = n.link >> 30, left = n.link & 0x3FFFFFFFu;
+                    float oa = sel3(axis, ox, oy, oz), ia = sel3(axis, ix, iy, iz);
+                    float tmid = (n.split - oa) * ia;
+                    uint32_t side = oa > n.split ? 1u : 0u;
+                    uint32_t nr = left + side, fr = left + 1u - side;
+                    if (!(tmid < ext) || tmid < 0.0f) {
+                        curr = nr;
+                    } else if (tmid <= ent) {
+                        curr = fr;
+                    } else {
+                        if (tmid < tmin) {
+                            stk[top * 64] = make_uint2(fr, __float_as_uint(ext));
+                            top = (top + 1) & (FS_SLOTS - 1);
+                            if (cnt == FS_SLOTS) dropped = true; else cnt++;
+                        }
+                        curr = nr;
+                        ext = tmid;
+                    }
+                }
+                if (++steps > FS_MAX_STEPS) done = true;
+                if (done) {
+                    Q.hits[r] = make_float4(tmin, hu, hv, __int_as_float(htri));
+                    active = false;
+                } else {
+                    n = S.nodeF[curr];
+                    ti = n.first; te = n.first + n.count;
+                    if (COUNT) { w_nodes++; w_tris += n.count; }
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        uint32_t w[2] = {w_nodes, w_tris};
+        for (int k = 0; k < 2; k++) {
+            uint32_t v = w[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) atomicAdd(&Q.work[k], (unsigned long long)v);
+        }
+    }
 }
 
 // ---- stage 3: shading of the GI hits ---------------------------------------------
@@ -326,7 +475,7 @@ __global__ void __launch_bounds__(64) k_shadow_gi(DevScene S, FastBuffers Q) {
         if (c > 0.0f) {                                           // a light behind the surface adds 0 whatever the shadow ray says
             HitF h;
             shadow++;
-            bool occluded = trace_f32<true>(S, pos.x, pos.y, pos.z, lx, ly, lz, dis, tri, stack + (threadIdx.x & 63), h);
+            bool occluded = trace_f32<true, false>(S, pos.x, pos.y, pos.z, lx, ly, lz, dis, tri, stack + (threadIdx.x & 63), h);
             if (!occluded) { dr += c * sr; dg += c * sg; db += c * sb; }
         }
     }
@@ -359,7 +508,7 @@ __global__ void __launch_bounds__(64) k_trace_fast_f64io(DevScene S, size_t n, c
     HitF h; h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
     double tm = tmin_in[k];
     float tmax = tm >= (double)FLT_MAX ? FLT_MAX : (float)tm;
-    bool ok = trace_f32<false>(S, (float)src[3 * k], (float)src[3 * k + 1], (float)src[3 * k + 2], (float)dir[3 * k],
+    bool ok = trace_f32<false, false>(S, (float)src[3 * k], (float)src[3 * k + 1], (float)src[3 * k + 2], (float)dir[3 * k],
                                (float)dir[3 * k + 1], (float)dir[3 * k + 2], tmax, -1, stack + (threadIdx.x & 63), h);
     found[k] = ok; tri[k] = h.tri; t[k] = ok ? (double)h.t : tm; u[k] = h.u; v[k] = h.v;
 }
@@ -377,14 +526,17 @@ int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *
     FA(sp_pos, float4); FA(sp_nrm, float4); FA(sp_base, float4); FA(contrib, float4);
 #undef FA
     if ((rc = alloc(ctx, 8 * sizeof(uint32_t), (void **)&Q.counts))) return rc;
+    if ((rc = alloc(ctx, 2 * sizeof(unsigned long long), (void **)&Q.work))) return rc;
     return PT_OK;
 }
 
 int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers &Q, int nsamples, int batch,
-            hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow) {
+            hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow,
+            uint64_t *work /* null, or [2]: nodes visited, triangles tested by the closest-hit launches */) {
     const int tthreads = tile_threads(V.size);
     const size_t P = (size_t)V.size * V.size;
     *trace_ms = 0; *launches = 0; *rays = 0; *shadow = 0;
+    if (work) FQ(hipMemsetAsync(Q.work, 0, 2 * sizeof(unsigned long long), s));
     for (int s0 = 0; s0 < nsamples; s0 += batch) {
         int nb = nsamples - s0 < batch ? nsamples - s0 : batch;
         if ((size_t)nb * P > Q.max_rays) return PT_ERR_LIMIT;
@@ -393,7 +545,11 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         FQ(hipMemsetAsync(Q.counts, 0, 8 * sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_gi_gen, dim3(blocks), dim3(64), 0, s, V, F, Q, s0, tthreads);
         FQ(hipEventRecord(e0, s));
-        hipLaunchKernelGGL(k_trace_closest, dim3(qblocks), dim3(64), 0, s, S, Q);
+        unsigned tblocks = qblocks < PT_TRACE_WAVES ? qblocks : PT_TRACE_WAVES;
+        if (work)
+            hipLaunchKernelGGL(k_trace_closest<true>, dim3(tblocks), dim3(64), 0, s, S, Q);
+        else
+            hipLaunchKernelGGL(k_trace_closest<false>, dim3(tblocks), dim3(64), 0, s, S, Q);
         FQ(hipEventRecord(e1, s));
         if (V.model == PT_MODEL_MAIN) {
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(qblocks), dim3(64), 0, s, S, Q);
@@ -410,6 +566,11 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         FQ(hipEventElapsedTime(&ms, e0, e1));
         *trace_ms += ms; (*launches)++;
         *rays += c[0]; *shadow += c[2];
+    }
+    if (work) {
+        unsigned long long w[2];
+        FQ(hipMemcpy(w, Q.work, sizeof w, hipMemcpyDeviceToHost));
+        work[0] = w[0]; work[1] = w[1];
     }
     return PT_OK;
 }

@@ -41,7 +41,8 @@ struct FastBuffers {
     float4 *sp_nrm;           // normal xyz, slot bits
     float4 *sp_base;          // r1 * 0.6 * txt * albedo / pi, unused
     float4 *contrib;          // per slot: r1 * radiance of the sample ray
-    uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2..] reserved
+    uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2] shadow rays traced, [3] queue head of the closest-hit kernel
+    unsigned long long *work; // [0] nodes visited, [1] triangles tested (counting build of the closest-hit kernel)
     size_t max_rays;
 };
 
@@ -65,6 +66,7 @@ int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *
 // All GI passes of one view: fills F.gi_acc.  trace_ms / launches: device time and
 // count of the closest-hit traversal launches; rays / shadow: query counts.
 int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers &Q, int nsamples, int batch,
-            hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow);
+            hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow,
+            uint64_t *work);
 int fast_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
                int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s);

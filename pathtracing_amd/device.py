@@ -20,7 +20,7 @@ FLT_MAX = float(np.finfo(np.float32).max)
 class PtOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("gi", C.c_int32), ("rb", C.c_int32), ("model", C.c_int32),
                 ("spp", C.c_int32), ("gi_precision", C.c_int32), ("seed", C.c_uint32), ("view", C.c_uint32),
-                ("size", C.c_int32)]
+                ("size", C.c_int32), ("flags", C.c_uint32)]
 
 
 class PtAov(C.Structure):
@@ -30,7 +30,7 @@ class PtAov(C.Structure):
 class PtStats(C.Structure):
     _fields_ = [("primary", C.c_uint64), ("shadow", C.c_uint64), ("mirror", C.c_uint64), ("gi", C.c_uint64),
                 ("omp_retrace", C.c_uint64), ("ms_total", C.c_double), ("ms_gi_trace", C.c_double),
-                ("gi_trace_launches", C.c_uint64)]
+                ("gi_trace_launches", C.c_uint64), ("gi_nodes_visited", C.c_uint64), ("gi_tris_tested", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -88,8 +88,12 @@ def make_camera(eye, angle, zoom):
     return PtCamera((C.c_double * 3)(*eye), angle, zoom)
 
 
-def make_options(gi=False, rb=False, model=MODEL_MAIN, spp=0, gi_precision=GI_F64_EXACT, seed=0x5EED, view=0, size=512):
-    return PtOptions(C.sizeof(PtOptions), int(gi), int(rb), model, spp, gi_precision, seed, view, size)
+FLAG_COUNT_WORK = 1
+
+
+def make_options(gi=False, rb=False, model=MODEL_MAIN, spp=0, gi_precision=GI_F64_EXACT, seed=0x5EED, view=0, size=512,
+                 flags=0):
+    return PtOptions(C.sizeof(PtOptions), int(gi), int(rb), model, spp, gi_precision, seed, view, size, flags)
 
 
 def scene_blob(desc):
