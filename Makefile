@@ -8,13 +8,13 @@ CC       ?= gcc
 PKG      := pathtracing_amd
 HOSTSRC  := $(wildcard $(PKG)/csrc/host/*.cpp)
 DEVDIR   := $(PKG)/csrc/device
-DEVOBJ   := $(DEVDIR)/pt_abi.o $(DEVDIR)/pt_exact.o $(DEVDIR)/pt_fast.o
+DEVOBJ   := $(DEVDIR)/pt_abi.o $(DEVDIR)/pt_exact.o $(DEVDIR)/pt_fast.o $(DEVDIR)/pt_refine.o
 DEVHDR   := $(wildcard $(PKG)/csrc/device/*.h) $(wildcard include/*.h)
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -Iinclude
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Wall
 # The fp64 reference-semantics kernels must round after every operation; the
 # fp32 GI kernels may fuse multiply-adds.
-$(DEVDIR)/pt_abi.o $(DEVDIR)/pt_exact.o: CONTRACT := -ffp-contract=off
+$(DEVDIR)/pt_abi.o $(DEVDIR)/pt_exact.o $(DEVDIR)/pt_refine.o: CONTRACT := -ffp-contract=off
 $(DEVDIR)/pt_fast.o: CONTRACT := -ffp-contract=fast
 
 all: host device cli oracle

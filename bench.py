@@ -218,7 +218,8 @@ def main():
             "data": "synthetic" if a.workload == "atrium" else "reference scene file, packed",
             "config": {"workload": WORKLOADS[a.workload][2], "spp": a.spp, "model": a.model, "rb": bool(a.rb),
                        "image": "512x512", "views_per_step": world, "parallelism": f"views round-robin over {world} GPU(s)",
-                       "triangles": st["triangles"], "kd_refs": st["optimized"], "kd_nodes": st["nodes"]},
+                       "triangles": st["triangles"], "kd_refs": st["optimized"], "kd_nodes": st["nodes"],
+                       "device_tree": ds.info()},
             "views_per_s": round(a.steps * world / dt_max, 3),
             "gi_mrays_per_s": round(gi_total / dt_max / 1e6, 1),
             "scene_setup_s": round(scene_seconds, 2),

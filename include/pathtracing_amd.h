@@ -132,6 +132,14 @@ const char *pt_version(void);
 int pt_scene_upload(const PtSceneDesc *desc, PtScene **out);
 int pt_scene_free(PtScene *scene);
 
+/* Sizes of the device copies.  dev_* describe the fp32 copy of the tree walked by
+   the GI fast path: the host's nodes plus the nodes made by subdividing fat leaves. */
+typedef struct PtSceneInfo {
+    uint64_t host_nodes, host_refs, dev_nodes, dev_refs, dev_leaves, dev_max_leaf, dev_interior_refs, dev_bytes;
+    int32_t host_depth, dev_depth;
+} PtSceneInfo;
+int pt_scene_info(const PtScene *scene, PtSceneInfo *out);
+
 /* Same, from / to one self-contained byte blob, so that one process can hand
    the scene to others (e.g. an RCCL broadcast) without re-reading files. */
 int pt_scene_blob_size(const PtSceneDesc *desc, size_t *bytes);

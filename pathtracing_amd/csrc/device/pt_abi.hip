@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -12,6 +13,7 @@
 
 #include "pathtracing_amd.h"
 #include "pt_frame.h"
+#include "pt_refine.h"
 
 #define PT_STACK_MAX 64   // per-lane stack of the fp64 search (pt_exact.h)
 
@@ -48,6 +50,8 @@ struct PtScene {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int max_depth = 0;
+    RefineStats refine;
+    uint64_t dev_bytes = 0;
     uint32_t n_tri = 0, n_mesh = 0;
     std::vector<int32_t> tri_mesh, tri_local;   // host copies for (mesh, tri) reporting
 };
@@ -60,6 +64,7 @@ int dev_copy(PtScene *sc, const T *src, size_t n, const T **out) {
     size_t bytes = (n ? n : 1) * sizeof(T);
     HIPCHK(hipMalloc(&d, bytes));
     sc->owned.push_back(d);
+    sc->dev_bytes += bytes;
     if (n) HIPCHK(hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
     *out = (const T *)d;
     return PT_OK;
@@ -172,30 +177,37 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     // ---- tree: fp64 traversal nodes + boxes, fp32 nodes ----
     std::vector<NodeA> na(d->n_node);
     std::vector<double> nbox((size_t)d->n_node * 6);
-    std::vector<NodeF> nf(d->n_node);
     for (uint32_t k = 0; k < d->n_node; k++) {
         const PtKdNode &n = d->nodes[k];
         na[k].split = n.split; na[k].axis = n.axis; na[k].left = n.left; na[k].first = n.first; na[k].count = n.count;
         for (int c = 0; c < 3; c++) { nbox[6 * (size_t)k + c] = n.lo[c]; nbox[6 * (size_t)k + 3 + c] = n.hi[c]; }
-        nf[k].split = (float)n.split;
-        nf[k].link = n.axis < 0 ? 0xFFFFFFFFu : ((uint32_t)n.left | ((uint32_t)n.axis << 30));
-        nf[k].first = (uint32_t)n.first;
-        nf[k].count = (uint32_t)n.count;
     }
-    if (d->n_node >= (1u << 30)) return bail(fail(PT_ERR_LIMIT, "more than 2^30 kd nodes"));
+    // ---- fp32 copy of the tree, fat leaves subdivided (pt_refine.hip) ----
+    std::vector<NodeF> nf;
+    std::vector<int32_t> frefs;
+    RefineParams rp;
+    if (const char *e = getenv("PT_TUNE_REFINE")) rp.enable = atoi(e) != 0;
+    if (const char *e = getenv("PT_TUNE_CI")) rp.ci = (float)atof(e);
+    if (const char *e = getenv("PT_TUNE_LEAF")) rp.leaf_keep = atoi(e);
+    sc->refine = refine_tree(d, rp, nf, frefs);
+    if (nf.size() >= (1u << 28) || (uint64_t)frefs.size() * 48u >= (1ull << 32))
+        return bail(fail(PT_ERR_LIMIT, "kd-tree too large for 32-bit byte offsets (2^28 nodes, 2^32 / 48 references)"));
     // ---- per-reference triangle data in node order: v0, v1 - v0, v2 - v0 ----
     std::vector<double> rt((size_t)d->n_ref * 9);
-    std::vector<float4> rtf((size_t)d->n_ref * 3);
-    for (uint32_t r = 0; r < d->n_ref; r++) {
-        int32_t t = d->refs[r];
+    auto tri9 = [&](int32_t t, double *o) {
         const double *a = d->vert + 3 * (size_t)d->tri_vi[3 * (size_t)t];
         const double *b = d->vert + 3 * (size_t)d->tri_vi[3 * (size_t)t + 1];
         const double *c = d->vert + 3 * (size_t)d->tri_vi[3 * (size_t)t + 2];
-        double *o = &rt[(size_t)r * 9];
         for (int k = 0; k < 3; k++) { o[k] = a[k]; o[3 + k] = b[k] - a[k]; o[6 + k] = c[k] - a[k]; }
-        rtf[3 * (size_t)r] = make_float4((float)o[0], (float)o[1], (float)o[2], bits_to_float(t));
-        rtf[3 * (size_t)r + 1] = make_float4((float)o[3], (float)o[4], (float)o[5], 0.f);
-        rtf[3 * (size_t)r + 2] = make_float4((float)o[6], (float)o[7], (float)o[8], 0.f);
+    };
+    for (uint32_t r = 0; r < d->n_ref; r++) tri9(d->refs[r], &rt[(size_t)r * 9]);
+    std::vector<float4> rtf(frefs.size() * 3);
+    for (size_t r = 0; r < frefs.size(); r++) {
+        double o[9];
+        tri9(frefs[r], o);
+        rtf[3 * r] = make_float4((float)o[0], (float)o[1], (float)o[2], bits_to_float(frefs[r]));
+        rtf[3 * r + 1] = make_float4((float)o[3], (float)o[4], (float)o[5], 0.f);
+        rtf[3 * r + 2] = make_float4((float)o[6], (float)o[7], (float)o[8], 0.f);
     }
     // ---- textures flattened into one byte pool ----
     std::vector<int64_t> toff(d->n_tex);
@@ -390,6 +402,17 @@ int pt_init(int device) {
 int pt_shutdown(void) { g_device = -1; return PT_OK; }
 
 int pt_scene_upload(const PtSceneDesc *desc, PtScene **out) { return upload(desc, out); }
+
+int pt_scene_info(const PtScene *sc, PtSceneInfo *out) {
+    if (!sc || !out) return fail(PT_ERR_INVALID, "pt_scene_info: null argument");
+    std::memset(out, 0, sizeof *out);
+    out->host_nodes = (uint64_t)sc->S.n_node; out->host_refs = (uint64_t)sc->S.n_ref;
+    out->dev_nodes = sc->refine.nodes; out->dev_refs = sc->refine.refs; out->dev_leaves = sc->refine.leaves;
+    out->dev_max_leaf = sc->refine.max_leaf; out->dev_interior_refs = sc->refine.interior_refs;
+    out->dev_bytes = sc->dev_bytes;
+    out->host_depth = sc->max_depth; out->dev_depth = sc->refine.max_depth;
+    return PT_OK;
+}
 
 int pt_scene_free(PtScene *sc) {
     if (!sc) return PT_OK;

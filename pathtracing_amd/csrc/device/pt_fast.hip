@@ -12,13 +12,14 @@
 // per wave.  Every sample owns a contribution slot, so the image does not depend
 // on the order in which waves append to the queues.
 #include <float.h>
+#include <stdlib.h>
 
 #include "pt_frame.h"
 #include "pt_vec.h"
 
 #pragma clang fp contract(fast)
 
-#define FS_SLOTS 16            // short-stack entries per lane (LDS); deeper pushes drop the oldest entry
+#define FS_SLOTS 8             // short-stack entries per lane (LDS); deeper pushes drop the oldest entry
 #define FS_MAX_STEPS 100000    // hard bound on node visits per ray: every wave terminates
 
 struct HitF { float t, u, v; int tri; };
@@ -199,12 +200,13 @@ __global__ void __launch_bounds__(64) k_gi_gen(ViewParams V, FrameBuffers F, Fas
 // from the queue head (one atomicAdd per wave, when at least PT_REFILL_MIN
 // lanes are idle).  A wave leaves when the queue is drained and all its lanes
 // are done, so the grid always drains.
-#define PT_REFILL_MIN 16
+#define PT_REFILL_MIN 8
+#define PT_QUEUE_CHUNK 128          // rays a wave takes from the queue head per atomicAdd (upper bound)
 #define PT_TRACE_WAVES (256 * 32)     // enough waves to fill every CU; surplus waves find the queue empty
 
 template <bool COUNT>
-__global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q) {
-    __shared__ uint2 stack[FS_SLOTS * 64];
+__global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
+    extern __shared__ uint2 stack[];            // (slot_mask + 1) * 64 entries
     const uint32_t lane = threadIdx.x & 63;
     uint2 *stk = stack + lane;
     const uint32_t n_rays = Q.counts[0];
@@ -212,7 +214,7 @@ __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q)
     const float hx = (float)S.root_hi[0], hy = (float)S.root_hi[1], hz = (float)S.root_hi[2];
 
     bool active = false, more = true;
-    uint32_t r = 0;
+    uint32_t r = 0, chunk_next = 0, chunk_end = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0;
     float tmin = 0, ent = 0, ext = 0, root_ext = 0, hu = 0, hv = 0;
     int htri = -1, skip = -1;
@@ -223,13 +225,25 @@ __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q)
 
     for (;;) {
         unsigned long long idle = __ballot(!active);
-        if (more && __popcll(idle) >= PT_REFILL_MIN) {
-            uint32_t want = (uint32_t)__popcll(idle), base = 0;
-            if (lane == 0) base = atomicAdd(&Q.counts[3], want);
-            base = __shfl(base, 0, 64);
-            if (base + want >= n_rays) more = false;
+        if (more && __popcll(idle) >= refill_min) {
+            // The wave owns a chunk [chunk_next, chunk_end) of the queue; one atomicAdd on
+            // the queue head buys a whole chunk, so the head is touched once per `chunk`
+            // rays instead of once per refill.
+            if (chunk_next == chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&Q.counts[3], chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                chunk_next = base < n_rays ? base : n_rays;
+                chunk_end = base + chunk < n_rays ? base + chunk : n_rays;
+                if (chunk_next == chunk_end) more = false;
+            }
+            uint32_t want = (uint32_t)__popcll(idle), have = chunk_end - chunk_next;
+            uint32_t take = want < have ? want : have;
+            uint32_t base = chunk_next;
+            chunk_next += take;
             if (!active) {
-                uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                uint32_t k = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                uint32_t mine = k < take ? base + k : n_rays;
                 if (mine < n_rays) {
                     r = mine;
                     float4 o = Q.rays_o[r], d = Q.rays_d[r];
@@ -262,12 +276,12 @@ __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q)
         if (active) {
             if (ti < te) {
                 // ---- one triangle of the current node ----
-                const float4 *tp = S.refTriF + (size_t)ti * 3;
+                const float4 *tp = (const float4 *)((const char *)S.refTriF + ti * 48u);   // 32-bit offset: < 2^32 bytes, checked at upload
                 float4 A = tp[0], B = tp[1], C = tp[2];
                 ti++;
                 float px = dy * C.z - dz * C.y, py = dz * C.x - dx * C.z, pz = dx * C.y - dy * C.x;
                 float det = px * B.x + py * B.y + pz * B.z;
-                float inv = 1.0f / det;
+                float inv = __builtin_amdgcn_rcpf(det);
                 float tx = ox - A.x, ty = oy - A.y, tz = oz - A.z;
                 float u = (px * tx + py * ty + pz * tz) * inv;
                 float qx = ty * B.z - tz * B.y, qy = tz * B.x - tx * B.z, qz = tx * B.y - ty * B.x;
@@ -285,7 +299,7 @@ __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q)
                     if (ent >= tmin) {
                         done = true;
                     } else if (cnt > 0) {
-                        top = (top - 1) & (FS_SLOTS - 1);
+                        top = (top - 1) & slot_mask;
                         cnt--;
                         uint2 e = stk[top * 64];
                         curr = e.x; ext = __uint_as_float(e.y);
@@ -308,8 +322,8 @@ __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q)
                     } else {
                         if (tmid < tmin) {
                             stk[top * 64] = make_uint2(fr, __float_as_uint(ext));
-                            top = (top + 1) & (FS_SLOTS - 1);
-                            if (cnt == FS_SLOTS) dropped = true; else cnt++;
+                            top = (top + 1) & slot_mask;
+                            if (cnt > slot_mask) dropped = true; else cnt++;
                         }
                         curr = nr;
                         ext = tmid;
@@ -320,7 +334,7 @@ __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q)
                     Q.hits[r] = make_float4(tmin, hu, hv, __int_as_float(htri));
                     active = false;
                 } else {
-                    n = S.nodeF[curr];
+                    n = *(const NodeF *)((const char *)S.nodeF + curr * 16u);
                     ti = n.first; te = n.first + n.count;
                     if (COUNT) { w_nodes++; w_tris += n.count; }
                 }
@@ -530,11 +544,28 @@ int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *
     return PT_OK;
 }
 
+// Launch parameters of the closest-hit kernel.  The defaults are what the
+// measurements in profiles/ were taken with; the PT_TUNE_* environment
+// variables exist for sweeps.
+struct TraceTune { int slots, refill, waves, chunk; };
+static TraceTune trace_tune() {
+    static TraceTune t = [] {
+        TraceTune v{FS_SLOTS, PT_REFILL_MIN, PT_TRACE_WAVES, PT_QUEUE_CHUNK};
+        if (const char *e = getenv("PT_TUNE_SLOTS")) { int k = atoi(e); if (k == 4 || k == 8 || k == 16 || k == 32) v.slots = k; }
+        if (const char *e = getenv("PT_TUNE_REFILL")) { int k = atoi(e); if (k >= 1 && k <= 64) v.refill = k; }
+        if (const char *e = getenv("PT_TUNE_CHUNK")) { int k = atoi(e); if (k >= 64 && k <= 65536) v.chunk = k; }
+        if (const char *e = getenv("PT_TUNE_WAVES")) { int k = atoi(e); if (k >= 64 && k <= (1 << 20)) v.waves = k; }
+        return v;
+    }();
+    return t;
+}
+
 int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers &Q, int nsamples, int batch,
             hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow,
             uint64_t *work /* null, or [2]: nodes visited, triangles tested by the closest-hit launches */) {
     const int tthreads = tile_threads(V.size);
     const size_t P = (size_t)V.size * V.size;
+    const TraceTune tune = trace_tune();
     *trace_ms = 0; *launches = 0; *rays = 0; *shadow = 0;
     if (work) FQ(hipMemsetAsync(Q.work, 0, 2 * sizeof(unsigned long long), s));
     for (int s0 = 0; s0 < nsamples; s0 += batch) {
@@ -545,11 +576,16 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         FQ(hipMemsetAsync(Q.counts, 0, 8 * sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_gi_gen, dim3(blocks), dim3(64), 0, s, V, F, Q, s0, tthreads);
         FQ(hipEventRecord(e0, s));
-        unsigned tblocks = qblocks < PT_TRACE_WAVES ? qblocks : PT_TRACE_WAVES;
+        unsigned tblocks = qblocks < (unsigned)tune.waves ? qblocks : (unsigned)tune.waves;
+        size_t lds = (size_t)tune.slots * 64 * sizeof(uint2);
+        // queue chunk per atomicAdd: large enough to keep the queue head cold, small enough
+        // that every resident wave gets several chunks
+        uint32_t chunk = (uint32_t)((P * nb) / ((size_t)tune.waves * 4));
+        chunk = chunk < 64 ? 64 : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
         if (work)
-            hipLaunchKernelGGL(k_trace_closest<true>, dim3(tblocks), dim3(64), 0, s, S, Q);
+            hipLaunchKernelGGL(k_trace_closest<true>, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
         else
-            hipLaunchKernelGGL(k_trace_closest<false>, dim3(tblocks), dim3(64), 0, s, S, Q);
+            hipLaunchKernelGGL(k_trace_closest<false>, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
         FQ(hipEventRecord(e1, s));
         if (V.model == PT_MODEL_MAIN) {
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(qblocks), dim3(64), 0, s, S, Q);

@@ -1,0 +1,183 @@
+// Device-side copy of the kd-tree for the fp32 GI path.
+//
+// The host hands over the reference's tree (centroid-sweep SAH, axis by depth,
+// pull-up; util/kdtree.cpp:88-172).  Its leaves are fat -- a leaf stops as soon
+// as the centroid heuristic sees no gain, so leaves of tens to hundreds of
+// triangles are common -- and on the GPU every triangle test is three divergent
+// 16-byte loads per lane, which is what the closest-hit kernel is bound by.
+// Flattening therefore subdivides every leaf that holds more than a few
+// triangles with a surface-area-heuristic sweep over the triangles' clipped
+// bounds on all three axes.  The upper tree (every node the host built) is kept
+// as it is, including the triangle lists pulled up into interior nodes, and the
+// traversal result is unchanged: a kd-tree only decides WHICH triangles are
+// tested, the nearest hit over them is the same.
+//
+// The fp64 reference-semantics path never sees this copy; it walks the host's
+// tree node for node.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "pt_refine.h"
+
+namespace {
+
+struct Box3 { float lo[3], hi[3]; };
+
+inline float area(const Box3 &b) {
+    float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+    return 2.0f * (x * y + y * z + z * x);
+}
+
+struct Builder {
+    const PtSceneDesc *d;
+    RefineParams prm;
+    std::vector<Box3> tbox;               // per triangle: bounds of its fp32 vertices, slightly widened
+    std::vector<NodeF> &nodes;
+    std::vector<int32_t> &refs;
+    RefineStats st{};
+
+    Builder(const PtSceneDesc *desc, const RefineParams &p, std::vector<NodeF> &n, std::vector<int32_t> &r)
+        : d(desc), prm(p), nodes(n), refs(r) {
+        tbox.resize(d->n_tri);
+        for (uint32_t t = 0; t < d->n_tri; t++) {
+            Box3 b;
+            for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; }
+            for (int c = 0; c < 3; c++) {
+                const double *v = d->vert + 3 * (size_t)d->tri_vi[3 * (size_t)t + c];
+                for (int k = 0; k < 3; k++) {
+                    float f = (float)v[k];
+                    b.lo[k] = std::min(b.lo[k], f);
+                    b.hi[k] = std::max(b.hi[k], f);
+                }
+            }
+            // the kernel intersects v0 + e1, v0 + e2 in fp32: allow for a few ulps of difference
+            for (int k = 0; k < 3; k++) {
+                float m = std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])) * 4.8e-7f + 1e-30f;
+                b.lo[k] -= m; b.hi[k] += m;
+            }
+            tbox[t] = b;
+        }
+    }
+
+    // Emit node `slot` for the triangles `ids` inside `box`; children go to fresh adjacent slots.
+    void build(uint32_t slot, const Box3 &box, std::vector<int32_t> &ids, int depth) {
+        const size_t n = ids.size();
+        int best_axis = -1;
+        float best_plane = 0, best_cost = prm.ci * (float)n;
+        if (n > (size_t)prm.leaf_keep && depth < prm.max_depth) {
+            const float sa = area(box);
+            std::vector<float> los(n), his(n);
+            for (int a = 0; a < 3 && sa > 0; a++) {
+                const float blo = box.lo[a], bhi = box.hi[a];
+                if (!(bhi > blo)) continue;
+                for (size_t i = 0; i < n; i++) {
+                    los[i] = std::max(tbox[ids[i]].lo[a], blo);
+                    his[i] = std::min(tbox[ids[i]].hi[a], bhi);
+                }
+                std::sort(los.begin(), los.end());
+                std::sort(his.begin(), his.end());
+                Box3 lb = box, rb = box;
+                // candidate planes: every clipped bound strictly inside the box
+                size_t il = 0, ih = 0;
+                auto consider = [&](float p) {
+                    if (!(p > blo && p < bhi)) return;
+                    // left gets triangles starting below p, right those ending above p
+                    while (il < n && los[il] < p) il++;
+                    while (ih < n && his[ih] <= p) ih++;
+                    size_t nl = il, nr = n - ih;
+                    lb.hi[a] = p; rb.lo[a] = p;
+                    float c = prm.ct + prm.ci * (area(lb) * (float)nl + area(rb) * (float)nr) / sa;
+                    if (nl == 0 || nr == 0) c *= prm.empty_bonus;
+                    if (c < best_cost) { best_cost = c; best_axis = a; best_plane = p; }
+                };
+                // merged ascending walk over both bound lists
+                size_t a_i = 0, b_i = 0;
+                while (a_i < n || b_i < n) {
+                    float p = (b_i >= n || (a_i < n && los[a_i] <= his[b_i])) ? los[a_i++] : his[b_i++];
+                    consider(p);
+                }
+            }
+        }
+        NodeF &o = nodes[slot];
+        if (best_axis < 0) {
+            o.split = 0; o.link = 0xFFFFFFFFu;
+            o.first = (uint32_t)refs.size(); o.count = (uint32_t)n;
+            refs.insert(refs.end(), ids.begin(), ids.end());
+            st.leaves++; st.leaf_refs += n;
+            st.max_leaf = std::max<uint64_t>(st.max_leaf, n);
+            st.max_depth = std::max(st.max_depth, depth);
+            return;
+        }
+        std::vector<int32_t> L, R;
+        for (int32_t t : ids) {
+            float lo = std::max(tbox[t].lo[best_axis], box.lo[best_axis]), hi = std::min(tbox[t].hi[best_axis], box.hi[best_axis]);
+            bool l = lo < best_plane, r = hi > best_plane;
+            if (!l && !r) l = true;                       // flat in the plane
+            if (l) L.push_back(t);
+            if (r) R.push_back(t);
+        }
+        std::vector<int32_t>().swap(ids);
+        uint32_t left = (uint32_t)nodes.size();
+        nodes.push_back(NodeF{});
+        nodes.push_back(NodeF{});
+        NodeF &o2 = nodes[slot];                          // nodes may have moved
+        o2.split = best_plane;
+        o2.link = left | ((uint32_t)best_axis << 30);
+        o2.first = (uint32_t)refs.size(); o2.count = 0;
+        st.new_nodes += 2;
+        Box3 lb = box, rb = box;
+        lb.hi[best_axis] = best_plane; rb.lo[best_axis] = best_plane;
+        build(left, lb, L, depth + 1);
+        build(left + 1, rb, R, depth + 1);
+    }
+};
+
+}  // namespace
+
+RefineStats refine_tree(const PtSceneDesc *d, const RefineParams &prm, std::vector<NodeF> &nodes, std::vector<int32_t> &refs) {
+    nodes.assign(d->n_node, NodeF{});
+    refs.clear();
+    refs.reserve((size_t)d->n_ref * 2);
+    Builder b(d, prm, nodes, refs);
+    // depth of every host node, for the depth bound of the subdivision
+    std::vector<int> depth(d->n_node, 0);
+    std::vector<uint32_t> order;
+    order.push_back(0);
+    for (size_t q = 0; q < order.size(); q++) {
+        const PtKdNode &n = d->nodes[order[q]];
+        if (n.axis >= 0) {
+            depth[n.left] = depth[n.left + 1] = depth[order[q]] + 1;
+            order.push_back((uint32_t)n.left);
+            order.push_back((uint32_t)n.left + 1);
+        }
+    }
+    for (uint32_t k : order) {
+        const PtKdNode &n = d->nodes[k];
+        if (n.axis >= 0) {                                 // interior node of the host tree: copied
+            NodeF &o = nodes[k];
+            o.split = (float)n.split;
+            o.link = (uint32_t)n.left | ((uint32_t)n.axis << 30);
+            o.first = (uint32_t)refs.size(); o.count = (uint32_t)n.count;
+            refs.insert(refs.end(), d->refs + n.first, d->refs + n.first + n.count);
+            b.st.interior_refs += (uint64_t)n.count;
+            continue;
+        }
+        std::vector<int32_t> ids(d->refs + n.first, d->refs + n.first + n.count);
+        Box3 box;
+        for (int c = 0; c < 3; c++) { box.lo[c] = (float)n.lo[c]; box.hi[c] = (float)n.hi[c]; }
+        if (!prm.enable) {
+            NodeF &o = nodes[k];
+            o.split = 0; o.link = 0xFFFFFFFFu; o.first = (uint32_t)refs.size(); o.count = (uint32_t)ids.size();
+            refs.insert(refs.end(), ids.begin(), ids.end());
+            b.st.leaves++; b.st.leaf_refs += ids.size();
+            b.st.max_leaf = std::max<uint64_t>(b.st.max_leaf, ids.size());
+            b.st.max_depth = std::max(b.st.max_depth, depth[k]);
+            continue;
+        }
+        b.build(k, box, ids, depth[k]);
+    }
+    b.st.nodes = nodes.size();
+    b.st.refs = refs.size();
+    return b.st;
+}

@@ -36,7 +36,12 @@ class PtStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-EXPORTS = ("pt_init", "pt_shutdown", "pt_last_error", "pt_version", "pt_scene_upload", "pt_scene_free",
+class PtSceneInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("host_nodes", "host_refs", "dev_nodes", "dev_refs", "dev_leaves", "dev_max_leaf",
+                                          "dev_interior_refs", "dev_bytes")] + [("host_depth", C.c_int32), ("dev_depth", C.c_int32)]
+
+
+EXPORTS = ("pt_scene_info", "pt_init", "pt_shutdown", "pt_last_error", "pt_version", "pt_scene_upload", "pt_scene_free",
            "pt_scene_blob_size", "pt_scene_blob_write", "pt_scene_upload_blob", "pt_render_view",
            "pt_render_view_device", "pt_render_views", "pt_trace", "pt_camera_rays", "pt_hemisphere_samples")
 
@@ -55,6 +60,7 @@ def lib():
         L.pt_init.argtypes = [C.c_int]
         L.pt_scene_upload.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(C.c_void_p)]
         L.pt_scene_free.argtypes = [C.c_void_p]
+        L.pt_scene_info.argtypes = [C.c_void_p, C.POINTER(PtSceneInfo)]
         L.pt_scene_blob_size.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(C.c_size_t)]
         L.pt_scene_blob_write.argtypes = [C.POINTER(PtSceneDesc), C.c_void_p, C.c_size_t]
         L.pt_scene_upload_blob.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -116,6 +122,11 @@ class DeviceScene:
         else:
             _check(lib().pt_scene_upload(C.byref(desc), C.byref(h)), "pt_scene_upload")
         self._h = h
+
+    def info(self):
+        i = PtSceneInfo()
+        _check(lib().pt_scene_info(self._h, C.byref(i)), "pt_scene_info")
+        return {k: getattr(i, k) for k, _ in PtSceneInfo._fields_}
 
     def render(self, eye, angle, zoom, aov=True, **opt):
         o = make_options(**opt)

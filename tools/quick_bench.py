@@ -15,4 +15,5 @@ for w in args:
     j = json.loads(line[-1])
     r = j["roofline"]
     print(f"{w}: value {j['value']} Mrays/s, kernel {r['kernel_mrays_per_s']} Mrays/s, ms/launch {r['ms_per_launch']}, "
-          f"nodes/ray {r['nodes_per_ray']}, tris/ray {r['tris_per_ray']}, frac {r['frac']}, ms/step {j['ms_per_step']}")
+          f"nodes/ray {r['nodes_per_ray']}, tris/ray {r['tris_per_ray']}, frac {r['frac']}, ms/step {j['ms_per_step']}, "
+          f"tree {j['config']['device_tree']['dev_nodes']}n/{j['config']['device_tree']['dev_refs']}r depth {j['config']['device_tree']['dev_depth']} setup {j['scene_setup_s']}s")
