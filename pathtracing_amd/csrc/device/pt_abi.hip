@@ -186,7 +186,8 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     std::vector<NodeF> nf;
     std::vector<int32_t> frefs;
     RefineParams rp;
-    if (const char *e = getenv("PT_TUNE_REFINE")) rp.enable = atoi(e) != 0;
+    // PT_TUNE_REFINE: 0 = the host tree as it is, 1 = host tree with subdivided leaves, 2 (default) = rebuilt
+    if (const char *e = getenv("PT_TUNE_REFINE")) { rp.enable = atoi(e) != 0; rp.rebuild = atoi(e) == 2; }
     if (const char *e = getenv("PT_TUNE_CI")) rp.ci = (float)atof(e);
     if (const char *e = getenv("PT_TUNE_LEAF")) rp.leaf_keep = atoi(e);
     sc->refine = refine_tree(d, rp, nf, frefs);
@@ -201,6 +202,7 @@ int upload(const PtSceneDesc *d, PtScene **out) {
         for (int k = 0; k < 3; k++) { o[k] = a[k]; o[3 + k] = b[k] - a[k]; o[6 + k] = c[k] - a[k]; }
     };
     for (uint32_t r = 0; r < d->n_ref; r++) tri9(d->refs[r], &rt[(size_t)r * 9]);
+    for (NodeF &n : nf) n = encode_node(n);
     std::vector<float4> rtf(frefs.size() * 3);
     for (size_t r = 0; r < frefs.size(); r++) {
         double o[9];

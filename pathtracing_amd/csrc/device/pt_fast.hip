@@ -2,132 +2,90 @@
 // useful sample count):
 //
 //   k_gi_gen        G-buffer + counter RNG -> compacted ray queue (SoA)
-//   k_trace_closest kd traversal, nearest hit, per-lane short stack in LDS
+//   k_trace_closest kd traversal, nearest hit: persistent waves, one unit of work per
+//                   lane per turn, per-lane short stack in LDS (pt_trace_f32.h)
 //   k_shade_gi      surface properties + lights; OMP model: writes the sample's
 //                   contribution; MAIN model: compacts hits into a shading-point queue
-//   k_shadow_gi     MAIN model: any-hit traversal towards every light
+//   k_shadow_gi     MAIN model: any-hit traversal towards every light (same machinery)
 //   k_gi_sum        ordered per-pixel sum of the pass's contributions (fp64)
 //
 // Compaction between stages is a wave ballot + prefix popcount + one atomicAdd
 // per wave.  Every sample owns a contribution slot, so the image does not depend
-// on the order in which waves append to the queues.
+// on the order in which waves append to or draw from the queues.
 #include <float.h>
 #include <stdlib.h>
 
 #include "pt_frame.h"
+#include "pt_trace_f32.h"
 #include "pt_vec.h"
 
 #pragma clang fp contract(fast)
 
-#define FS_SLOTS 8             // short-stack entries per lane (LDS); deeper pushes drop the oldest entry
-#define FS_MAX_STEPS 100000    // hard bound on node visits per ray: every wave terminates
+#define FS_SLOTS 8                  // ring entries per lane in LDS (one of them is kept free)
+#define PT_REFILL_MIN 8             // idle lanes that trigger a refill
+#define PT_QUEUE_CHUNK 128          // work items a wave takes from the queue head per atomicAdd (upper bound)
+#define PT_TRACE_WAVES (256 * 32)   // enough waves to fill every CU; surplus waves find the queue empty
 
-struct HitF { float t, u, v; int tri; };
-
-__device__ __forceinline__ float sel3(uint32_t a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
-
-// Nearest hit (ANY = false) or first hit (ANY = true) of the ray o + t*d, 0 < t < tmax,
-// ignoring triangle `skip`.  Triangles referenced by interior nodes are tested on
-// the way down; a leaf's triangles when it is reached.  Front-to-back order with
-// the exit test "segment start >= best t" makes the result the exact nearest hit
-// over the triangles of all visited nodes.
-//
-// The stack holds (far child, far segment end) only: a popped segment starts
-// where the previous leaf's segment ended.  It is a ring of FS_SLOTS entries per
-// lane in LDS; when it overflows the oldest entry is dropped and, once the ring
-// runs empty, traversal restarts from the root at the current segment start.
-//
-// COUNT adds two per-lane counters (nodes visited, triangles tested) for the
-// work census that prices the kernel's algorithmic bytes; the timed build has
-// COUNT = false.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool trace_f32(const DevScene &S, float ox, float oy, float oz, float dx, float dy, float dz,
-                                          float tmax, int skip, uint2 *stk, HitF &h, uint32_t *work = nullptr) {
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    float ent, ext;
-    {
-        float lx = (float)S.root_lo[0], ly = (float)S.root_lo[1], lz = (float)S.root_lo[2];
-        float hx = (float)S.root_hi[0], hy = (float)S.root_hi[1], hz = (float)S.root_hi[2];
-        float a0 = (lx - ox) * ix, a1 = (hx - ox) * ix;
-        float b0 = (ly - oy) * iy, b1 = (hy - oy) * iy;
-        float c0 = (lz - oz) * iz, c1 = (hz - oz) * iz;
-        ent = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-        ext = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tmax));
-        if (!(ent <= ext)) return false;
-    }
-    const float root_ext = ext;
-    float tmin = tmax;
-    bool found = false;
-    uint32_t curr = 0, top = 0, cnt = 0;
-    bool dropped = false;
-    int steps = 0;
+// ---- the persistent loop ---------------------------------------------------------------
+// Work items 0 .. n_items-1 are drawn from *head in chunks (one atomicAdd per chunk
+// per wave, so the head word is touched once per `chunk` items, not once per refill).
+// Policy::start(item, L, box) fetches an item and begins its first ray (false: the
+// item needed no traversal and is complete); Policy::finish(L, box) consumes a
+// finished ray and either begins another ray of the same item (true) or completes
+// the item (false).  A wave leaves when the queue is drained and all of its lanes
+// are done, so the grid always drains.
+template <bool ANY, bool COUNT, class Policy>
+__device__ __forceinline__ void persistent_trace(const DevScene &S, Policy &P, uint32_t n_items, uint32_t *head, uint32_t chunk,
+                                                 int refill_min, uint32_t slot_mask, uint2 *stack,
+                                                 unsigned long long *work_out) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint2 *stk = stack + lane;
+    const RootBox box = root_box(S);
+    LaneState L;
+    L.toff = L.tend = 0; L.nlink = 0xFFFFFFFFu; L.nsplit = 0;
+    bool active = false, more = true;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    uint32_t work[2] = {0, 0};
     for (;;) {
-        NodeF n = S.nodeF[curr];
-        for (;;) {
-            if (COUNT) { work[0]++; work[1] += n.count; }
-            if (n.count) {
-                // The next triangle's 48 bytes are requested before the current one is
-                // tested, so that two loads per lane are in flight along the list.
-                const float4 *tp = S.refTriF + (size_t)n.first * 3;
-                float4 A = tp[0], B = tp[1], C = tp[2];
-                for (uint32_t i = 0; i < n.count; i++) {
-                    tp += (i + 1 < n.count) ? 3 : 0;
-                    float4 An = tp[0], Bn = tp[1], Cn = tp[2];
-                    float px = dy * C.z - dz * C.y, py = dz * C.x - dx * C.z, pz = dx * C.y - dy * C.x;
-                    float det = px * B.x + py * B.y + pz * B.z;
-                    float inv = 1.0f / det;
-                    float tx = ox - A.x, ty = oy - A.y, tz = oz - A.z;
-                    float u = (px * tx + py * ty + pz * tz) * inv;
-                    float qx = ty * B.z - tz * B.y, qy = tz * B.x - tx * B.z, qz = tx * B.y - ty * B.x;
-                    float v = (qx * dx + qy * dy + qz * dz) * inv;
-                    float t = (qx * C.x + qy * C.y + qz * C.z) * inv;
-                    int id = __float_as_int(A.w);
-                    if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > 0.0f && t < tmin && id != skip) {
-                        tmin = t; h.t = t; h.u = u; h.v = v; h.tri = id;
-                        found = true;
-                        if (ANY) return true;
-                    }
-                    A = An; B = Bn; C = Cn;
+        const unsigned long long idle = __ballot(!active);
+        if (more && __popcll(idle) >= refill_min) {
+            if (chunk_next == chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                chunk_next = base < n_items ? base : n_items;
+                chunk_end = base + chunk < n_items ? base + chunk : n_items;
+                if (chunk_next == chunk_end) more = false;
+            }
+            const uint32_t want = (uint32_t)__popcll(idle), have = chunk_end - chunk_next;
+            const uint32_t take = want < have ? want : have, base = chunk_next;
+            chunk_next += take;
+            if (!active) {
+                const uint32_t k = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (k < take) {
+                    active = P.start(base + k, L, box);
+                    if (COUNT && active) { work[0]++; work[1] += (L.tend - L.toff) / 48u; }
                 }
             }
-            if (n.link == 0xFFFFFFFFu) break;
-            uint32_t axis = n.link >> 30, left = n.link & 0x3FFFFFFFu;
-            float oa = sel3(axis, ox, oy, oz), ia = sel3(axis, ix, iy, iz);
-            float tmid = (n.split - oa) * ia;
-            uint32_t side = oa > n.split ? 1u : 0u;
-            uint32_t nr = left + side, fr = left + 1u - side;
-            if (!(tmid < ext) || tmid < 0.0f) {
-                curr = nr;
-            } else if (tmid <= ent) {
-                curr = fr;
-            } else {
-                if (tmid < tmin) {
-                    stk[top * 64] = make_uint2(fr, __float_as_uint(ext));
-                    top = (top + 1) & (FS_SLOTS - 1);
-                    if (cnt == FS_SLOTS) dropped = true; else cnt++;
-                }
-                curr = nr;
-                ext = tmid;
+        }
+        if (!__any(active)) {
+            if (!more) break;
+            continue;
+        }
+        if (active) {
+            if (lane_turn<ANY, COUNT>(L, S, stk, slot_mask, work)) {
+                active = P.finish(L, box);
+                if (COUNT && active) { work[0]++; work[1] += (L.tend - L.toff) / 48u; }
             }
-            n = S.nodeF[curr];
-            if (++steps > FS_MAX_STEPS) return found;
         }
-        ent = ext;                       // the next segment starts where this leaf's ended
-        if (ent >= tmin) break;
-        if (cnt > 0) {
-            top = (top - 1) & (FS_SLOTS - 1);
-            cnt--;
-            uint2 e = stk[top * 64];
-            curr = e.x; ext = __uint_as_float(e.y);
-        } else if (dropped) {
-            dropped = false;
-            curr = 0; ext = root_ext;
-        } else {
-            break;
-        }
-        if (++steps > FS_MAX_STEPS) break;
     }
-    return found;
+    if (COUNT) {
+        for (int k = 0; k < 2; k++) {
+            uint32_t v = work[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) atomicAdd(&work_out[k], (unsigned long long)v);
+        }
+    }
 }
 
 // ---- stage 1: ray generation from the G-buffer --------------------------------
@@ -170,7 +128,7 @@ __global__ void __launch_bounds__(64) k_gi_gen(ViewParams V, FrameBuffers F, Fas
         if (valid) {
             double r1;
             D3 w = gi_direction(dload(F.gnrm + 3 * p), V.seed, V.view, (uint32_t)p, (uint32_t)(s0 + sl), r1);
-            ro = make_float4((float)hit.x, (float)hit.y, (float)hit.z, FLT_MAX);
+            ro = make_float4((float)hit.x, (float)hit.y, (float)hit.z, __int_as_float(F.rec_tri[p]));
             rd = make_float4((float)w.x, (float)w.y, (float)w.z, (float)r1);
         } else {
             Q.contrib[(size_t)sl * P + p] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -186,169 +144,32 @@ __global__ void __launch_bounds__(64) k_gi_gen(ViewParams V, FrameBuffers F, Fas
         Q.rays_o[r] = ro;
         Q.rays_d[r] = rd;
         Q.ray_slot[r] = (uint32_t)((size_t)sl * P + p);
-        Q.ray_skip[r] = F.rec_tri[p];
     }
 }
 
 // ---- stage 2: closest hit -------------------------------------------------------
-// Persistent waves.  Rays differ a lot in length (a ray that threads a cluster
-// of fat leaves costs tens of times the mean), so a wave that owned 64 fixed
-// rays would idle most of its lanes most of the time.  Instead every lane runs
-// a small state machine and advances by ONE unit per loop turn -- one triangle
-// test if its current node still has untested triangles, else one node step
-// (descend / pop / restart) -- and lanes whose ray is finished draw new rays
-// from the queue head (one atomicAdd per wave, when at least PT_REFILL_MIN
-// lanes are idle).  A wave leaves when the queue is drained and all its lanes
-// are done, so the grid always drains.
-#define PT_REFILL_MIN 8
-#define PT_QUEUE_CHUNK 128          // rays a wave takes from the queue head per atomicAdd (upper bound)
-#define PT_TRACE_WAVES (256 * 32)     // enough waves to fill every CU; surplus waves find the queue empty
+struct ClosestPolicy {
+    const DevScene &S;
+    const FastBuffers &Q;
+    uint32_t r;
+    __device__ __forceinline__ bool start(uint32_t item, LaneState &L, const RootBox &box) {
+        r = item;
+        const float4 o = Q.rays_o[r], d = Q.rays_d[r];
+        if (lane_begin(L, S, box, o.x, o.y, o.z, d.x, d.y, d.z, FLT_MAX, __float_as_int(o.w))) return true;
+        Q.hits[r] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        return false;
+    }
+    __device__ __forceinline__ bool finish(LaneState &L, const RootBox &) {
+        Q.hits[r] = make_float4(L.tmin, L.hu, L.hv, __int_as_float(L.htri));
+        return false;
+    }
+};
 
 template <bool COUNT>
 __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
     extern __shared__ uint2 stack[];            // (slot_mask + 1) * 64 entries
-    const uint32_t lane = threadIdx.x & 63;
-    uint2 *stk = stack + lane;
-    const uint32_t n_rays = Q.counts[0];
-    const float lx = (float)S.root_lo[0], ly = (float)S.root_lo[1], lz = (float)S.root_lo[2];
-    const float hx = (float)S.root_hi[0], hy = (float)S.root_hi[1], hz = (float)S.root_hi[2];
-
-    bool active = false, more = true;
-    uint32_t r = 0, chunk_next = 0, chunk_end = 0;
-    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0;
-    float tmin = 0, ent = 0, ext = 0, root_ext = 0, hu = 0, hv = 0;
-    int htri = -1, skip = -1;
-    uint32_t curr = 0, top = 0, cnt = 0, ti = 0, te = 0, steps = 0;
-    bool dropped = false;
-    NodeF n; n.split = 0; n.link = 0xFFFFFFFFu; n.first = 0; n.count = 0;
-    uint32_t w_nodes = 0, w_tris = 0;
-
-    for (;;) {
-        unsigned long long idle = __ballot(!active);
-        if (more && __popcll(idle) >= refill_min) {
-            // The wave owns a chunk [chunk_next, chunk_end) of the queue; one atomicAdd on
-            // the queue head buys a whole chunk, so the head is touched once per `chunk`
-            // rays instead of once per refill.
-            if (chunk_next == chunk_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&Q.counts[3], chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                chunk_next = base < n_rays ? base : n_rays;
-                chunk_end = base + chunk < n_rays ? base + chunk : n_rays;
-                if (chunk_next == chunk_end) more = false;
-            }
-            uint32_t want = (uint32_t)__popcll(idle), have = chunk_end - chunk_next;
-            uint32_t take = want < have ? want : have;
-            uint32_t base = chunk_next;
-            chunk_next += take;
-            if (!active) {
-                uint32_t k = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                uint32_t mine = k < take ? base + k : n_rays;
-                if (mine < n_rays) {
-                    r = mine;
-                    float4 o = Q.rays_o[r], d = Q.rays_d[r];
-                    skip = Q.ray_skip[r];
-                    ox = o.x; oy = o.y; oz = o.z; dx = d.x; dy = d.y; dz = d.z;
-                    ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
-                    float a0 = (lx - ox) * ix, a1 = (hx - ox) * ix;
-                    float b0 = (ly - oy) * iy, b1 = (hy - oy) * iy;
-                    float c0 = (lz - oz) * iz, c1 = (hz - oz) * iz;
-                    ent = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-                    ext = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), o.w));
-                    tmin = o.w; htri = -1; hu = 0; hv = 0;
-                    if (ent <= ext) {
-                        active = true;
-                        root_ext = ext;
-                        curr = 0; top = 0; cnt = 0; dropped = false; steps = 0;
-                        n = S.nodeF[0];
-                        ti = n.first; te = n.first + n.count;
-                        if (COUNT) { w_nodes++; w_tris += n.count; }
-                    } else {
-                        Q.hits[r] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                    }
-                }
-            }
-        }
-        if (!__any(active)) {
-            if (!more) break;
-            continue;
-        }
-        if (active) {
-            if (ti < te) {
-                // ---- one triangle of the current node ----
-                const float4 *tp = (const float4 *)((const char *)S.refTriF + ti * 48u);   // 32-bit offset: < 2^32 bytes, checked at upload
-                float4 A = tp[0], B = tp[1], C = tp[2];
-                ti++;
-                float px = dy * C.z - dz * C.y, py = dz * C.x - dx * C.z, pz = dx * C.y - dy * C.x;
-                float det = px * B.x + py * B.y + pz * B.z;
-                float inv = __builtin_amdgcn_rcpf(det);
-                float tx = ox - A.x, ty = oy - A.y, tz = oz - A.z;
-                float u = (px * tx + py * ty + pz * tz) * inv;
-                float qx = ty * B.z - tz * B.y, qy = tz * B.x - tx * B.z, qz = tx * B.y - ty * B.x;
-                float v = (qx * dx + qy * dy + qz * dz) * inv;
-                float t = (qx * C.x + qy * C.y + qz * C.z) * inv;
-                int id = __float_as_int(A.w);
-                if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > 0.0f && t < tmin && id != skip) {
-                    tmin = t; hu = u; hv = v; htri = id;
-                }
-            } else {
-                // ---- one node step ----
-                bool done = false;
-                if (n.link == 0xFFFFFFFFu) {
-                    ent = ext;                      // the next segment starts where this leaf's ended
-                    if (ent >= tmin) {
-                        done = true;
-                    } else if (cnt > 0) {
-                        top = (top - 1) & slot_mask;
-                        cnt--;
-                        uint2 e = stk[top * 64];
-                        curr = e.x; ext = __uint_as_float(e.y);
-                    } else if (dropped) {
-                        dropped = false;
-                        curr = 0; ext = root_ext;
-                    } else {
-                        done = true;
-                    }
-                } else {
-                    uint32_t axis = n.link >> 30, left = n.link & 0x3FFFFFFFu;
-                    float oa = sel3(axis, ox, oy, oz), ia = sel3(axis, ix, iy, iz);
-                    float tmid = (n.split - oa) * ia;
-                    uint32_t side = oa > n.split ? 1u : 0u;
-                    uint32_t nr = left + side, fr = left + 1u - side;
-                    if (!(tmid < ext) || tmid < 0.0f) {
-                        curr = nr;
-                    } else if (tmid <= ent) {
-                        curr = fr;
-                    } else {
-                        if (tmid < tmin) {
-                            stk[top * 64] = make_uint2(fr, __float_as_uint(ext));
-                            top = (top + 1) & slot_mask;
-                            if (cnt > slot_mask) dropped = true; else cnt++;
-                        }
-                        curr = nr;
-                        ext = tmid;
-                    }
-                }
-                if (++steps > FS_MAX_STEPS) done = true;
-                if (done) {
-                    Q.hits[r] = make_float4(tmin, hu, hv, __int_as_float(htri));
-                    active = false;
-                } else {
-                    n = *(const NodeF *)((const char *)S.nodeF + curr * 16u);
-                    ti = n.first; te = n.first + n.count;
-                    if (COUNT) { w_nodes++; w_tris += n.count; }
-                }
-            }
-        }
-    }
-    if (COUNT) {
-        uint32_t w[2] = {w_nodes, w_tris};
-        for (int k = 0; k < 2; k++) {
-            uint32_t v = w[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) atomicAdd(&Q.work[k], (unsigned long long)v);
-        }
-    }
+    ClosestPolicy P{S, Q, 0};
+    persistent_trace<false, COUNT>(S, P, Q.counts[0], &Q.counts[3], chunk, refill_min, slot_mask, stack, Q.work);
 }
 
 // ---- stage 3: shading of the GI hits ---------------------------------------------
@@ -474,29 +295,52 @@ __global__ void __launch_bounds__(64) k_shade_gi(DevScene S, FastBuffers Q) {
 }
 
 // ---- stage 4 (MAIN model): shadow rays of the GI hits ------------------------------
-__global__ void __launch_bounds__(64) k_shadow_gi(DevScene S, FastBuffers Q) {
-    __shared__ uint2 stack[FS_SLOTS * 64];
-    uint32_t q = blockIdx.x * 64 + threadIdx.x;
-    if (q >= Q.counts[1]) return;
-    float4 pos = Q.sp_pos[q], nrm = Q.sp_nrm[q], base = Q.sp_base[q];
-    int tri = __float_as_int(pos.w);
-    uint32_t shadow = 0;
-    float dr = 0, dg = 0, db = 0;
-    for (int k = 0; k < S.n_light; k++) {
-        float lx, ly, lz, dis, sr, sg, sb;
-        light_f(S.lights[k], pos.x, pos.y, pos.z, lx, ly, lz, dis, sr, sg, sb);
-        float c = lx * nrm.x + ly * nrm.y + lz * nrm.z;
-        if (c > 0.0f) {                                           // a light behind the surface adds 0 whatever the shadow ray says
-            HitF h;
-            shadow++;
-            bool occluded = trace_f32<true, false>(S, pos.x, pos.y, pos.z, lx, ly, lz, dis, tri, stack + (threadIdx.x & 63), h);
-            if (!occluded) { dr += c * sr; dg += c * sg; db += c * sb; }
+// One work item = one shading point; its lights are visited in order by the same lane.
+struct ShadowPolicy {
+    const DevScene &S;
+    const FastBuffers &Q;
+    float px, py, pz, nx, ny, nz, br, bg, bb, dr, dg, db, c, sr, sg, sb;
+    int tri, k;
+    uint32_t slot, shadow;
+    // Find the next light in front of the surface and begin its shadow ray; complete the
+    // point when there is none (a light behind the surface adds 0 whatever its ray says).
+    __device__ __forceinline__ bool next_light(LaneState &L, const RootBox &box) {
+        for (; k < S.n_light; k++) {
+            float lx, ly, lz, dis;
+            light_f(S.lights[k], px, py, pz, lx, ly, lz, dis, sr, sg, sb);
+            c = lx * nx + ly * ny + lz * nz;
+            if (c > 0.0f) {
+                shadow++;
+                if (lane_begin(L, S, box, px, py, pz, lx, ly, lz, dis, tri)) return true;
+                dr += c * sr; dg += c * sg; db += c * sb;             // ray misses the scene box: visible
+            }
         }
+        Q.contrib[slot] = make_float4(br * dr, bg * dg, bb * db, 0.f);
+        return false;
     }
-    Q.contrib[__float_as_uint(nrm.w)] = make_float4(base.x * dr, base.y * dg, base.z * db, 0.f);
-    // shadow-ray census: one atomic per wave
-    for (int o = 32; o > 0; o >>= 1) shadow += __shfl_xor(shadow, o, 64);
-    if ((threadIdx.x & 63) == 0 && shadow) atomicAdd(&Q.counts[2], shadow);
+    __device__ __forceinline__ bool start(uint32_t item, LaneState &L, const RootBox &box) {
+        const float4 pos = Q.sp_pos[item], nrm = Q.sp_nrm[item], base = Q.sp_base[item];
+        px = pos.x; py = pos.y; pz = pos.z; tri = __float_as_int(pos.w);
+        nx = nrm.x; ny = nrm.y; nz = nrm.z; slot = __float_as_uint(nrm.w);
+        br = base.x; bg = base.y; bb = base.z;
+        dr = dg = db = 0.f; k = 0;
+        return next_light(L, box);
+    }
+    __device__ __forceinline__ bool finish(LaneState &L, const RootBox &box) {
+        if (L.htri < 0) { dr += c * sr; dg += c * sg; db += c * sb; }
+        k++;
+        return next_light(L, box);
+    }
+};
+
+__global__ void __launch_bounds__(64) k_shadow_gi(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
+    extern __shared__ uint2 stack[];
+    ShadowPolicy P{S, Q};
+    P.shadow = 0;
+    persistent_trace<true, false>(S, P, Q.counts[1], &Q.counts[4], chunk, refill_min, slot_mask, stack, nullptr);
+    uint32_t n = P.shadow;
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&Q.counts[2], n);
 }
 
 // ---- stage 5: indirect += r1 * L over the pass's samples, in sample order ------------
@@ -513,18 +357,36 @@ __global__ void k_gi_sum(FrameBuffers F, FastBuffers Q, int size, int nb, int fi
 }
 
 // ---- raw queries for tests: fp64 in/out around the fp32 traversal -------------------
-__global__ void __launch_bounds__(64) k_trace_fast_f64io(DevScene S, size_t n, const double *src, const double *dir,
+struct RawPolicy {
+    const DevScene &S;
+    const double *src, *dir, *tmin_in;
+    int32_t *found, *tri;
+    double *t, *u, *v;
+    size_t k;
+    __device__ __forceinline__ void miss() { found[k] = 0; tri[k] = -1; t[k] = tmin_in[k]; u[k] = 0; v[k] = 0; }
+    __device__ __forceinline__ bool start(uint32_t item, LaneState &L, const RootBox &box) {
+        k = item;
+        double tm = tmin_in[k];
+        float tmax = tm >= (double)FLT_MAX ? FLT_MAX : (float)tm;
+        if (lane_begin(L, S, box, (float)src[3 * k], (float)src[3 * k + 1], (float)src[3 * k + 2], (float)dir[3 * k],
+                       (float)dir[3 * k + 1], (float)dir[3 * k + 2], tmax, -1))
+            return true;
+        miss();
+        return false;
+    }
+    __device__ __forceinline__ bool finish(LaneState &L, const RootBox &) {
+        if (L.htri < 0) { miss(); return false; }
+        found[k] = 1; tri[k] = L.htri; t[k] = (double)L.tmin; u[k] = (double)L.hu; v[k] = (double)L.hv;
+        return false;
+    }
+};
+
+__global__ void __launch_bounds__(64) k_trace_fast_f64io(DevScene S, uint32_t n, uint32_t *head, const double *src, const double *dir,
                                                          const double *tmin_in, int32_t *found, int32_t *tri, double *t,
-                                                         double *u, double *v) {
-    __shared__ uint2 stack[FS_SLOTS * 64];
-    size_t k = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (k >= n) return;
-    HitF h; h.t = 0; h.u = 0; h.v = 0; h.tri = -1;
-    double tm = tmin_in[k];
-    float tmax = tm >= (double)FLT_MAX ? FLT_MAX : (float)tm;
-    bool ok = trace_f32<false, false>(S, (float)src[3 * k], (float)src[3 * k + 1], (float)src[3 * k + 2], (float)dir[3 * k],
-                               (float)dir[3 * k + 1], (float)dir[3 * k + 2], tmax, -1, stack + (threadIdx.x & 63), h);
-    found[k] = ok; tri[k] = h.tri; t[k] = ok ? (double)h.t : tm; u[k] = h.u; v[k] = h.v;
+                                                         double *u, double *v, uint32_t slot_mask) {
+    extern __shared__ uint2 stack[];
+    RawPolicy P{S, src, dir, tmin_in, found, tri, t, u, v, 0};
+    persistent_trace<false, false>(S, P, n, head, 64u, 1, slot_mask, stack, nullptr);
 }
 
 // ---- host side ------------------------------------------------------------------------
@@ -536,7 +398,7 @@ int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *
     Q.max_rays = n;
     int rc;
 #define FA(field, type) if ((rc = alloc(ctx, n * sizeof(type), (void **)&Q.field))) return rc
-    FA(rays_o, float4); FA(rays_d, float4); FA(ray_slot, uint32_t); FA(ray_skip, int32_t); FA(hits, float4);
+    FA(rays_o, float4); FA(rays_d, float4); FA(ray_slot, uint32_t); FA(hits, float4);
     FA(sp_pos, float4); FA(sp_nrm, float4); FA(sp_base, float4); FA(contrib, float4);
 #undef FA
     if ((rc = alloc(ctx, 8 * sizeof(uint32_t), (void **)&Q.counts))) return rc;
@@ -589,7 +451,7 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         FQ(hipEventRecord(e1, s));
         if (V.model == PT_MODEL_MAIN) {
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(qblocks), dim3(64), 0, s, S, Q);
-            hipLaunchKernelGGL(k_shadow_gi, dim3(qblocks), dim3(64), 0, s, S, Q);
+            hipLaunchKernelGGL(k_shadow_gi, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
         } else {
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_OMP>, dim3(qblocks), dim3(64), 0, s, S, Q);
         }
@@ -613,6 +475,18 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
 
 int fast_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
                int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s) {
-    hipLaunchKernelGGL(k_trace_fast_f64io, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, S, n, src, dir, tmin_in, found, tri, t, u, v);
-    return hipGetLastError() == hipSuccess ? PT_OK : PT_ERR_HIP;
+    uint32_t *head = nullptr;
+    if (hipMalloc((void **)&head, sizeof(uint32_t)) != hipSuccess) return PT_ERR_HIP;
+    hipError_t e = hipMemsetAsync(head, 0, sizeof(uint32_t), s);
+    const TraceTune tune = trace_tune();
+    unsigned blocks = (unsigned)((n + 63) / 64);
+    if (blocks > (unsigned)tune.waves) blocks = (unsigned)tune.waves;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_trace_fast_f64io, dim3(blocks), dim3(64), (size_t)tune.slots * 64 * sizeof(uint2), s, S, (uint32_t)n, head,
+                           src, dir, tmin_in, found, tri, t, u, v, (uint32_t)tune.slots - 1u);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(head);
+    return e == hipSuccess ? PT_OK : PT_ERR_HIP;
 }

@@ -32,16 +32,15 @@ struct FrameBuffers {
 
 // Queues and slots of the fp32 GI wavefront path (pt_fast.hip).
 struct FastBuffers {
-    float4 *rays_o;           // origin xyz, tmax
+    float4 *rays_o;           // origin xyz, index bits of the triangle the ray starts on (never reported as a hit)
     float4 *rays_d;           // direction xyz, weight r1 (cos theta)
     uint32_t *ray_slot;       // contribution slot = sample_in_pass * P + pixel
-    int32_t *ray_skip;        // triangle the ray starts on (never reported as a hit)
     float4 *hits;             // t, u, v, triangle index bits (-1: miss)
     float4 *sp_pos;           // shading points (MAIN model): position xyz, triangle index bits
     float4 *sp_nrm;           // normal xyz, slot bits
     float4 *sp_base;          // r1 * 0.6 * txt * albedo / pi, unused
     float4 *contrib;          // per slot: r1 * radiance of the sample ray
-    uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2] shadow rays traced, [3] queue head of the closest-hit kernel
+    uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2] shadow rays traced, [3] / [4] queue heads of the closest-hit / shadow kernels
     unsigned long long *work; // [0] nodes visited, [1] triangles tested (counting build of the closest-hit kernel)
     size_t max_rays;
 };

@@ -8,8 +8,9 @@
 
 struct RefineParams {
     bool enable = true;
+    bool rebuild = true;        // build the whole fp32 tree from the triangles (false: keep the host tree, subdivide its leaves)
     float ct = 1.0f;            // cost of one traversal step
-    float ci = 2.0f;            // cost of one triangle test
+    float ci = 1.2f;            // cost of one triangle test
     float empty_bonus = 0.8f;   // factor on splits that cut off empty space
     int leaf_keep = 2;          // leaves with at most this many triangles are left alone
     int max_depth = 56;         // depth bound, counted from the root of the host tree

@@ -1,19 +1,24 @@
-// Device-side copy of the kd-tree for the fp32 GI path.
+// Device-side kd-tree of the fp32 GI path.
 //
 // The host hands over the reference's tree (centroid-sweep SAH, axis by depth,
-// pull-up; util/kdtree.cpp:88-172).  Its leaves are fat -- a leaf stops as soon
-// as the centroid heuristic sees no gain, so leaves of tens to hundreds of
-// triangles are common -- and on the GPU every triangle test is three divergent
-// 16-byte loads per lane, which is what the closest-hit kernel is bound by.
-// Flattening therefore subdivides every leaf that holds more than a few
-// triangles with a surface-area-heuristic sweep over the triangles' clipped
-// bounds on all three axes.  The upper tree (every node the host built) is kept
-// as it is, including the triangle lists pulled up into interior nodes, and the
-// traversal result is unchanged: a kd-tree only decides WHICH triangles are
-// tested, the nearest hit over them is the same.
+// pull-up; util/kdtree.cpp:88-172).  The fp64 reference-semantics path walks that
+// tree node for node, because the reference's results depend on it.  The GI
+// sample rays only need the nearest hit, which no kd-tree changes -- a tree
+// decides WHICH triangles are tested, not what the nearest one is -- and on the
+// GPU the price of a tree is plain: every triangle test is three divergent
+// 16-byte loads per lane plus ~45 VALU instructions, every node step one load
+// plus ~45.  The reference's tree is expensive in those terms (leaves stop as
+// soon as the centroid heuristic sees no gain, so leaves of tens to hundreds of
+// triangles are common; the split axis is fixed by depth; triangles pulled up
+// into interior nodes are tested by every ray that passes).
 //
-// The fp64 reference-semantics path never sees this copy; it walks the host's
-// tree node for node.
+// Three variants, selected at upload (PT_TUNE_REFINE, for the ablation in DESIGN.md):
+//   0  the host tree as it is;
+//   1  the host tree, every leaf with more than a few triangles subdivided;
+//   2  (default) a tree built from the triangles: surface-area-heuristic sweep over
+//      the triangles' clipped bounds on all three axes, empty-space bonus.
+// Measured on MI355X, closest-hit kernel, 64 spp: atrium-262k 0.91 / 1.69 / 2.6
+// Grays/s, car 2.9 / 4.8 / 7.2 Grays/s.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -151,6 +156,18 @@ RefineStats refine_tree(const PtSceneDesc *d, const RefineParams &prm, std::vect
             order.push_back((uint32_t)n.left);
             order.push_back((uint32_t)n.left + 1);
         }
+    }
+    if (prm.rebuild) {
+        // Experiment: ignore the host tree and build the whole tree with the sweep above.
+        nodes.assign(1, NodeF{});
+        std::vector<int32_t> all(d->n_tri);
+        for (uint32_t t = 0; t < d->n_tri; t++) all[t] = (int32_t)t;
+        Box3 box;
+        for (int c = 0; c < 3; c++) { box.lo[c] = (float)d->nodes[0].lo[c]; box.hi[c] = (float)d->nodes[0].hi[c]; }
+        b.build(0, box, all, 0);
+        b.st.nodes = nodes.size();
+        b.st.refs = refs.size();
+        return b.st;
     }
     for (uint32_t k : order) {
         const PtKdNode &n = d->nodes[k];

@@ -16,15 +16,23 @@ struct NodeA {
     int32_t count;
 };
 
-// fp32 node of the GI fast path, 16 bytes, four to a 64-byte line.
-//   interior: split, left | axis << 30, first, count
-//   leaf    : split unused, 0xFFFFFFFF marker in `link`
+// fp32 node of the GI fast path, 16 bytes, four to a 64-byte line (layout and
+// encoding: pt_trace_f32.h).  While the tree is being built `link` holds
+// (left child index | axis << 30) and first/count index the reference list;
+// encode_node() turns that into the byte-offset form the kernels read.
 struct NodeF {
     float split;
-    uint32_t link;      // interior: left child index (30 bits) | axis << 30; leaf: 0xFFFFFFFFu
-    uint32_t first;
-    uint32_t count;
+    uint32_t link;      // built: left | axis << 30, leaf 0xFFFFFFFF; encoded: left * 16 | axis, leaf 0xFFFFFFFF
+    uint32_t first;     // built: first reference;              encoded: byte offset of the first triangle record
+    uint32_t count;     // built: number of references;         encoded: byte offset one past the last record
 };
+static inline NodeF encode_node(NodeF n) {
+    NodeF o = n;
+    if (n.link != 0xFFFFFFFFu) o.link = ((n.link & 0x3FFFFFFFu) << 4) | (n.link >> 30);
+    o.first = n.first * 48u;
+    o.count = (n.first + n.count) * 48u;
+    return o;
+}
 
 struct DevScene {
     // ---- fp64 reference-semantics path ----

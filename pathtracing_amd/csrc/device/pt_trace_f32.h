@@ -1,0 +1,140 @@
+// fp32 kd traversal as a per-lane state machine, and the persistent-wave loop
+// that drives it.
+//
+// Why this shape.  Rays differ a lot in length (a ray that threads a cluster of
+// fat nodes costs tens of times the mean), and the lanes of a wave are in
+// different nodes all the time.  A wave that owned 64 fixed rays and ran
+// "descend ... test leaf" loops would keep ~4 % of its lanes busy (measured).
+// Here every lane advances by ONE unit per turn of the loop -- one triangle
+// test if its current node still has untested triangles, else one node step
+// (descend / pop / restart) -- and a lane whose ray is finished takes the next
+// one from the work source.  Both unit kinds are straight-line, predicated code.
+//
+// Node record (16 bytes, four to a 64-byte line):
+//   split | link | tri_off | tri_end
+//   link    : 0xFFFFFFFF for a leaf, else (byte offset of the left child) | axis;
+//             children are adjacent, right = left + 16 bytes
+//   tri_off : byte offset of the node's first 48-byte triangle record
+//   tri_end : byte offset one past its last
+// Triangle record (48 bytes): v0.xyz, triangle index | e1.xyz, 0 | e2.xyz, 0.
+//
+// The traversal is an exact nearest-hit search over the triangles of all visited
+// nodes: triangles held by interior nodes are tested on the way down, a leaf's
+// when it is reached; segments are visited front to back and the search ends when
+// the next segment starts at or behind the best hit.  The stack holds (far child,
+// far segment end) only -- a popped segment starts where the previous leaf's
+// segment ended -- in a ring of `slots` entries per lane in LDS.  When the ring is
+// full the oldest entry is dropped and, once the ring runs empty, traversal
+// restarts from the root at the current segment start (short stack + restart).
+#pragma once
+#include <float.h>
+#include <hip/hip_runtime.h>
+
+#include "pt_scene_dev.h"
+
+#define FS_MAX_STEPS 200000    // hard bound on node steps per ray: every lane, so every wave, terminates
+
+struct LaneState {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
+    float tmin, ent, ext, root_ext, hu, hv;
+    int htri, skip;
+    uint32_t top, cnt, steps, dropped;
+    float nsplit;                       // current node
+    uint32_t nlink, toff, tend;
+};
+
+struct RootBox { float lx, ly, lz, hx, hy, hz; };
+
+__device__ __forceinline__ RootBox root_box(const DevScene &S) {
+    RootBox b;
+    b.lx = (float)S.root_lo[0]; b.ly = (float)S.root_lo[1]; b.lz = (float)S.root_lo[2];
+    b.hx = (float)S.root_hi[0]; b.hy = (float)S.root_hi[1]; b.hz = (float)S.root_hi[2];
+    return b;
+}
+
+__device__ __forceinline__ float sel3(uint32_t a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
+
+__device__ __forceinline__ void load_node(LaneState &L, const DevScene &S, uint32_t off) {
+    const uint4 n = *(const uint4 *)((const char *)S.nodeF + off);
+    L.nsplit = __uint_as_float(n.x); L.nlink = n.y; L.toff = n.z; L.tend = n.w;
+}
+
+// Start a ray; false when it misses the scene's box (nothing to traverse).
+__device__ __forceinline__ bool lane_begin(LaneState &L, const DevScene &S, const RootBox &b, float ox, float oy, float oz,
+                                           float dx, float dy, float dz, float tmax, int skip) {
+    L.ox = ox; L.oy = oy; L.oz = oz; L.dx = dx; L.dy = dy; L.dz = dz;
+    L.ix = __builtin_amdgcn_rcpf(dx); L.iy = __builtin_amdgcn_rcpf(dy); L.iz = __builtin_amdgcn_rcpf(dz);
+    float a0 = (b.lx - ox) * L.ix, a1 = (b.hx - ox) * L.ix;
+    float b0 = (b.ly - oy) * L.iy, b1 = (b.hy - oy) * L.iy;
+    float c0 = (b.lz - oz) * L.iz, c1 = (b.hz - oz) * L.iz;
+    L.ent = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+    L.ext = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tmax));
+    L.tmin = tmax; L.htri = -1; L.hu = 0; L.hv = 0; L.skip = skip;
+    L.root_ext = L.ext;
+    L.top = 0; L.cnt = 0; L.steps = 0; L.dropped = 0;
+    if (!(L.ent <= L.ext)) return false;
+    load_node(L, S, 0);
+    return true;
+}
+
+// One unit of work for this lane.  Returns true when the ray is finished
+// (nearest hit in tmin / hu / hv / htri, htri < 0 for a miss; with ANY the first
+// hit found ends the ray).  `stk` points at this lane's column of the LDS ring,
+// entries 64 apart; slot_mask = slots - 1.  One slot is kept free so that the
+// push below can be an unconditional store.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2 *stk, uint32_t slot_mask, uint32_t *work) {
+    if (L.toff < L.tend) {
+        // ---- one triangle of the current node (Moeller-Trumbore, two-sided) ----
+        const float4 *tp = (const float4 *)((const char *)S.refTriF + L.toff);
+        const float4 A = tp[0], B = tp[1], C = tp[2];
+        L.toff += 48u;
+        float px = L.dy * C.z - L.dz * C.y, py = L.dz * C.x - L.dx * C.z, pz = L.dx * C.y - L.dy * C.x;
+        float det = px * B.x + py * B.y + pz * B.z;
+        float inv = __builtin_amdgcn_rcpf(det);
+        float tx = L.ox - A.x, ty = L.oy - A.y, tz = L.oz - A.z;
+        float u = (px * tx + py * ty + pz * tz) * inv;
+        float qx = ty * B.z - tz * B.y, qy = tz * B.x - tx * B.z, qz = tx * B.y - ty * B.x;
+        float v = (qx * L.dx + qy * L.dy + qz * L.dz) * inv;
+        float t = (qx * C.x + qy * C.y + qz * C.z) * inv;
+        int id = __float_as_int(A.w);
+        // every comparison is false for a NaN, so a degenerate triangle never hits
+        bool hit = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f) & (t < L.tmin) & (id != L.skip);
+        L.tmin = hit ? t : L.tmin; L.hu = hit ? u : L.hu; L.hv = hit ? v : L.hv; L.htri = hit ? id : L.htri;
+        return ANY && hit;
+    }
+    // ---- one node step ----
+    const bool leaf = L.nlink == 0xFFFFFFFFu;
+    const uint32_t axis = L.nlink & 3u, left = L.nlink & ~15u;
+    const float oa = sel3(axis, L.ox, L.oy, L.oz), ia = sel3(axis, L.ix, L.iy, L.iz);
+    const float tmid = (L.nsplit - oa) * ia;
+    const uint32_t side = oa > L.nsplit ? 16u : 0u;
+    const uint32_t nr = left + side, fr = left + 16u - side;
+    const bool near_only = !(tmid < L.ext) | (tmid < 0.0f);     // also when tmid is NaN (ray in the split plane)
+    const bool far_only = !near_only & (tmid <= L.ent);
+    const bool both = !near_only & !far_only;
+    const bool push = !leaf & both & (tmid < L.tmin);
+    // leaf: the next segment starts where this one ended
+    const bool finished = leaf & (L.ext >= L.tmin);
+    const bool cont = leaf & !finished;
+    const bool pop = cont & (L.cnt > 0);
+    const bool restart = cont & (L.cnt == 0) & (L.dropped != 0);
+    const bool exhausted = cont & (L.cnt == 0) & (L.dropped == 0);
+    const uint32_t ptop = (L.top - 1u) & slot_mask;
+    const uint2 e = stk[ptop * 64];                                // harmless when not popping
+    stk[L.top * 64] = make_uint2(fr, __float_as_uint(L.ext));      // slot `top` is always free
+    const bool full = L.cnt == slot_mask;
+    const uint32_t curr = leaf ? (pop ? e.x : 0u) : (far_only ? fr : nr);
+    const float next_ext = leaf ? (pop ? __uint_as_float(e.y) : L.root_ext) : (both ? tmid : L.ext);
+    L.ent = leaf ? L.ext : L.ent;
+    L.ext = next_ext;
+    // ring bookkeeping: a push onto a full ring overwrites the oldest entry (the free slot moves on)
+    L.top = push ? ((L.top + 1u) & slot_mask) : (pop ? ptop : L.top);
+    L.cnt = push ? (full ? L.cnt : L.cnt + 1u) : (pop ? L.cnt - 1u : L.cnt);
+    L.dropped = restart ? 0u : ((push & full) ? 1u : L.dropped);
+    L.steps++;
+    const bool done = finished | exhausted | (L.steps > FS_MAX_STEPS);
+    load_node(L, S, done ? 0u : curr);
+    if (COUNT && !done) { work[0]++; work[1] += (L.tend - L.toff) / 48u; }
+    return done;
+}
