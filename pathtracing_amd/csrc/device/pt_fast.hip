@@ -9,8 +9,8 @@
 //   k_shadow_gi     MAIN model: any-hit traversal towards every light (same machinery)
 //   k_gi_sum        ordered per-pixel sum of the pass's contributions (fp64)
 //
-// Compaction between stages is a wave ballot + prefix popcount + one atomicAdd
-// per wave.  Every sample owns a contribution slot, so the image does not depend
+// Compaction between stages is a wave ballot + prefix popcount, a scan over the
+// block's waves in LDS and one atomicAdd per 1024-thread block.  Every sample owns a contribution slot, so the image does not depend
 // on the order in which waves append to or draw from the queues.
 #include <float.h>
 #include <stdlib.h>
@@ -88,6 +88,27 @@ __device__ __forceinline__ void persistent_trace(const DevScene &S, Policy &P, u
     }
 }
 
+// Queue append for a whole workgroup: ballot + prefix popcount inside each wave, a
+// scan over the block's waves in LDS, ONE atomicAdd per block.  (One atomicAdd per
+// wave on a single word saturates at ~90 per microsecond chip-wide, which is 3 ms
+// for the 262 144 waves of a 16 M-ray pass.)  Every thread of the block must call it.
+#define PT_APPEND_BLOCK 1024
+__device__ __forceinline__ uint32_t block_append(bool valid, uint32_t *counter) {
+    __shared__ uint32_t wave_n[PT_APPEND_BLOCK / 64];
+    __shared__ uint32_t block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned long long mask = __ballot(valid);
+    if (lane == 0) wave_n[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < nw; w++) { uint32_t c = wave_n[w]; wave_n[w] = tot; tot += c; }
+        block_base = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    return block_base + wave_n[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
 // ---- stage 1: ray generation from the G-buffer --------------------------------
 __device__ __forceinline__ bool tile_pixel_f(int linear, int size, int &i, int &j) {
     int tiles_x = (size + 7) >> 3;
@@ -114,12 +135,12 @@ __device__ __forceinline__ D3 gi_direction(D3 nrm, uint32_t seed, uint32_t view,
               sm.x * Nb.z + sm.y * nrm.z + sm.z * Nt.z);
 }
 
-__global__ void __launch_bounds__(64) k_gi_gen(ViewParams V, FrameBuffers F, FastBuffers Q, int s0, int tthreads) {
-    int lin = blockIdx.x * 64 + threadIdx.x;
-    int sl = lin / tthreads;
-    int i, j;
-    bool live = tile_pixel_f(lin - sl * tthreads, V.size, i, j);
-    size_t P = (size_t)V.size * V.size, p = live ? (size_t)i * V.size + j : 0;
+__global__ void __launch_bounds__(PT_APPEND_BLOCK) k_gi_gen(ViewParams V, FrameBuffers F, FastBuffers Q, int s0, int tthreads, int nb) {
+    const size_t lin = (size_t)blockIdx.x * PT_APPEND_BLOCK + threadIdx.x;
+    const int sl = (int)(lin / (size_t)tthreads);
+    int i = 0, j = 0;
+    const bool live = sl < nb && tile_pixel_f((int)(lin - (size_t)sl * tthreads), V.size, i, j);
+    const size_t P = (size_t)V.size * V.size, p = live ? (size_t)i * V.size + j : 0;
     bool valid = false;
     float4 ro, rd;
     if (live) {
@@ -134,13 +155,8 @@ __global__ void __launch_bounds__(64) k_gi_gen(ViewParams V, FrameBuffers F, Fas
             Q.contrib[(size_t)sl * P + p] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    unsigned long long mask = __ballot(valid);
-    int lane = threadIdx.x & 63;
-    uint32_t n = (uint32_t)__popcll(mask), base = 0;
-    if (lane == 0 && n) base = atomicAdd(&Q.counts[0], n);
-    base = __shfl(base, 0, 64);
+    const uint32_t r = block_append(valid, &Q.counts[0]);
     if (valid) {
-        uint32_t r = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         Q.rays_o[r] = ro;
         Q.rays_d[r] = rd;
         Q.ray_slot[r] = (uint32_t)((size_t)sl * P + p);
@@ -243,8 +259,8 @@ __device__ __forceinline__ void light_f(const PtLight &L, float hx, float hy, fl
 }
 
 template <int MODEL>
-__global__ void __launch_bounds__(64) k_shade_gi(DevScene S, FastBuffers Q) {
-    uint32_t r = blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBuffers Q) {
+    uint32_t r = blockIdx.x * PT_APPEND_BLOCK + threadIdx.x;
     bool in_range = r < Q.counts[0];
     bool hit = false;
     float4 sp_pos, sp_nrm, sp_base;
@@ -282,15 +298,8 @@ __global__ void __launch_bounds__(64) k_shade_gi(DevScene S, FastBuffers Q) {
         }
     }
     if (MODEL == PT_MODEL_MAIN) {
-        unsigned long long mask = __ballot(hit);
-        int lane = threadIdx.x & 63;
-        uint32_t n = (uint32_t)__popcll(mask), base = 0;
-        if (lane == 0 && n) base = atomicAdd(&Q.counts[1], n);
-        base = __shfl(base, 0, 64);
-        if (hit) {
-            uint32_t q = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            Q.sp_pos[q] = sp_pos; Q.sp_nrm[q] = sp_nrm; Q.sp_base[q] = sp_base;
-        }
+        const uint32_t q = block_append(hit, &Q.counts[1]);
+        if (hit) { Q.sp_pos[q] = sp_pos; Q.sp_nrm[q] = sp_nrm; Q.sp_base[q] = sp_base; }
     }
 }
 
@@ -433,10 +442,11 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
     for (int s0 = 0; s0 < nsamples; s0 += batch) {
         int nb = nsamples - s0 < batch ? nsamples - s0 : batch;
         if ((size_t)nb * P > Q.max_rays) return PT_ERR_LIMIT;
-        unsigned blocks = (unsigned)(((size_t)tthreads * nb) / 64);
+        unsigned blocks = (unsigned)(((size_t)tthreads * nb + PT_APPEND_BLOCK - 1) / PT_APPEND_BLOCK);
+        unsigned sblocks = (unsigned)((P * nb + PT_APPEND_BLOCK - 1) / PT_APPEND_BLOCK);
         unsigned qblocks = (unsigned)((P * nb + 63) / 64);
         FQ(hipMemsetAsync(Q.counts, 0, 8 * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_gi_gen, dim3(blocks), dim3(64), 0, s, V, F, Q, s0, tthreads);
+        hipLaunchKernelGGL(k_gi_gen, dim3(blocks), dim3(PT_APPEND_BLOCK), 0, s, V, F, Q, s0, tthreads, nb);
         FQ(hipEventRecord(e0, s));
         unsigned tblocks = qblocks < (unsigned)tune.waves ? qblocks : (unsigned)tune.waves;
         size_t lds = (size_t)tune.slots * 64 * sizeof(uint2);
@@ -450,10 +460,10 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
             hipLaunchKernelGGL(k_trace_closest<false>, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
         FQ(hipEventRecord(e1, s));
         if (V.model == PT_MODEL_MAIN) {
-            hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(qblocks), dim3(64), 0, s, S, Q);
+            hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(sblocks), dim3(PT_APPEND_BLOCK), 0, s, S, Q);
             hipLaunchKernelGGL(k_shadow_gi, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
         } else {
-            hipLaunchKernelGGL(k_shade_gi<PT_MODEL_OMP>, dim3(qblocks), dim3(64), 0, s, S, Q);
+            hipLaunchKernelGGL(k_shade_gi<PT_MODEL_OMP>, dim3(sblocks), dim3(PT_APPEND_BLOCK), 0, s, S, Q);
         }
         hipLaunchKernelGGL(k_gi_sum, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, F, Q, V.size, nb, s0 == 0);
         FQ(hipGetLastError());
