@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--model", default="omp", choices=["main", "omp"])
     ap.add_argument("--rb", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=8, help="image rows of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,7 +90,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from pathtracing_amd import device
+    from pathtracing_amd import device, multiview
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU")
     torch.cuda.set_device(local_rank)
@@ -108,19 +108,8 @@ def main():
         blob = device.scene_blob(hs.desc())
         cams = np.array([[*v.eye, v.angle, v.zoom] for v in views])
     if world > 1:
-        meta = torch.zeros(2, dtype=torch.int64, device=dev)
-        if rank == 0:
-            meta[0], meta[1] = blob.size, len(cams)
-        dist.broadcast(meta, 0)
-        d_blob = torch.empty(int(meta[0]), dtype=torch.uint8, device=dev)
-        d_cams = torch.empty((int(meta[1]), 5), dtype=torch.float64, device=dev)
-        if rank == 0:
-            d_blob.copy_(torch.from_numpy(blob))
-            d_cams.copy_(torch.from_numpy(cams))
-        dist.broadcast(d_blob, 0)           # the scene + kd-tree travel over xGMI once
-        dist.broadcast(d_cams, 0)
-        blob = d_blob.cpu().numpy()
-        cams = d_cams.cpu().numpy()
+        blob = multiview.broadcast_bytes(blob if rank == 0 else None, dev, dist)   # the scene + kd-tree travel over xGMI once
+        cams = multiview.broadcast_cameras(cams if rank == 0 else None, dev, dist)
     ds = device.DeviceScene(blob=blob)
     scene_seconds = time.time() - t_scene
     views = [device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])) for c in cams]
@@ -129,13 +118,13 @@ def main():
     size = 512
     opt = dict(gi=True, rb=a.rb, model=model, spp=a.spp, gi_precision=device.GI_F32_FAST, size=size)
     frame = torch.empty(size * size * 3, dtype=torch.uint8, device=dev)
-    gathered = [torch.empty_like(frame) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather = multiview.FrameGather(frame.numel(), dev, dist) if world > 1 else None
 
     def step(i, stats):
         v = (i * world + rank) % nviews
         ds.render_to_device(views[v], frame.data_ptr(), stats=stats, view=v, **opt)
         if world > 1:
-            dist.gather(frame, gathered, dst=0)   # finished frames go to rank 0
+            gather.gather(frame, i, nviews)       # finished frames go to rank 0
 
     def sync():
         if world > 1:
@@ -196,16 +185,20 @@ def main():
             orc = po.OracleScene(packed_path)
             if tmp:
                 os.remove(tmp)
-            cores = min(16, os.cpu_count() or 1, a.cpu_rows)
+            cores = min(16, os.cpu_count() or 1)
             v0 = views[a.warmup % nviews]
-            r = orc.render(eye=list(v0.eye), angle=v0.angle, zoom=v0.zoom, model=po.MODEL_OMP if a.model == "omp" else po.MODEL_MAIN,
-                           gi=True, rb=a.rb, spp=a.spp, rng=po.RNG_PHILOX, view=a.warmup % nviews, size=size,
-                           row0=size // (2 * a.cpu_rows), row_step=size // a.cpu_rows, nrows_limit=a.cpu_rows,
-                           threads=cores, aov=False)
+            okw = dict(eye=list(v0.eye), angle=v0.angle, zoom=v0.zoom, model=po.MODEL_OMP if a.model == "omp" else po.MODEL_MAIN,
+                       gi=True, rb=a.rb, spp=a.spp, rng=po.RNG_PHILOX, view=a.warmup % nviews, size=size, threads=cores, aov=False)
+            # one row per thread first, to size the sample for about --cpu-seconds of CPU work
+            probe = orc.render(row0=size // (2 * cores), row_step=size // cores, nrows_limit=cores, **okw)
+            rows = int(min(size, max(cores, cores * round(a.cpu_seconds / max(probe["seconds"], 1e-3)))))
+            rows = max(cores, (rows // cores) * cores)
+            step_rows = max(1, size // rows)
+            r = orc.render(row0=step_rows // 2, row_step=step_rows, nrows_limit=rows, **okw)
             crays = sum(v["searches"] for k, v in r["counts"].items() if k != "omp_retrace")
             cpu = {"value": round(crays / r["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                   "sample": f"{a.cpu_rows} of 512 image rows (every {size // a.cpu_rows}th) of one view at the same spp, "
-                             f"{crays} rays in {r['seconds']:.1f} s"}
+                   "sample": f"{rows} of 512 image rows (every {step_rows}th) of one view at the same spp: "
+                             f"{crays} rays in {r['seconds']:.1f} s on {cores} threads"}
 
         out = {
             "metric": "Mrays/s (all ray classes of -gi views; GI sample rays dominate)",
