@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round profile: kernel trace + stats and PMC passes of `bench.py` for one workload.
+# usage (on the GPU box): tools/make_profile.sh <workload> <tag>     -> gpurun_out/profile_<tag>/
+set -u
+W=${1:-atrium}
+TAG=${2:-$W}
+OUT=gpurun_out/profile_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ARGS="bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k -- python3 $ARGS > "$OUT/trace.log" 2>&1 || { echo "kernel trace failed"; exit 1; }
+grep "^{" "$OUT/trace.log" > "$OUT/bench_under_trace.json"
+run() {
+  name=$1; shift
+  timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- python3 $ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; return 1; }
+  echo "pass $name ok"
+}
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE && \
+run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT && \
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum && \
+run fetch FETCH_SIZE && \
+run write WRITE_SIZE && \
+run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_BUSY_avr
+python3 tools/pmc_summary.py "$OUT" "k_trace_closest<false>" > "$OUT/pmc_k_trace_closest.txt"
+python3 tools/pmc_summary.py "$OUT" "k_primary_exact" > "$OUT/pmc_k_primary_exact.txt"
+ls "$OUT/trace"
