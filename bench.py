@@ -39,6 +39,28 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, spec
 
 
+def pmc_traffic(workload, rays_per_launch):
+    """HBM-side bytes per launch of k_trace_closest from the committed PMC passes (profiles/), or None.
+    FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies wide reads at half size, hence the factor 2."""
+    best = None
+    for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        f = os.path.join(ROOT, "profiles", rnd, workload, "pmc_k_trace_closest.txt")
+        if os.path.exists(f):
+            best = f
+    if best is None:
+        return None
+    vals = {}
+    for line in open(best):
+        t = line.split()
+        if len(t) >= 4 and t[-1].startswith("mean="):
+            vals[t[0]] = float(t[-1][5:])
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    # the passes were collected at 16 777 216-ray launches; scale if this run's launches differ
+    scale = rays_per_launch / 16777216.0
+    return round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 * scale / 1e9, 2), os.path.relpath(best, ROOT)
+
+
 def load_host_scene(name):
     from pathtracing_amd import host
     packed, path_file, _ = WORKLOADS[name]
@@ -73,7 +95,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("PT_BENCH_WORKLOAD", "atrium"), choices=sorted(WORKLOADS))
-    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--spp", type=int, default=1024, help="GI samples per pixel (the reference's converged sponza/room renders use 1024)")
     ap.add_argument("--model", default="omp", choices=["main", "omp"])
     ap.add_argument("--rb", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -165,12 +187,16 @@ def main():
         rays_launch = stats.gi / launches
         achieved = bytes_per_ray * rays_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_unit": "GB per launch",
                     "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(n_node, 2),
                     "tris_per_ray": round(n_tri, 2), "rays_per_launch": int(rays_launch),
                     "ms_per_launch": round(ms_launch, 4),
                     "kernel_mrays_per_s": round(rays_launch / (ms_launch * 1e-3) / 1e6, 1) if ms_launch > 0 else 0.0}
 
+        tr = pmc_traffic(a.workload, rays_launch)
+        if tr:
+            roofline["traffic"], roofline["traffic_source"] = tr
+            roofline["algorithmic_gb_per_launch"] = round(bytes_per_ray * rays_launch / 1e9, 2)
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             from oracle import ptoracle as po
