@@ -35,9 +35,10 @@ float bits_to_float(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
     } while (0)
 
 struct Workspace {
-    int size = 0, batch = 0;
+    int size = 0, batch = 0, nsub = 0;
     FrameBuffers F{};
     FastBuffers Q{};
+    SubBuffers B{};
     std::vector<void *> owned;
 };
 
@@ -264,12 +265,15 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     return PT_OK;
 }
 
-int ensure_workspace(PtScene *sc, int size, int batch, bool fast) {
+int ensure_workspace(PtScene *sc, int size, int batch, bool fast, int nsub) {
     Workspace &ws = sc->ws;
     bool have_fast = ws.Q.rays_o != nullptr;
-    if (ws.size == size && ws.batch >= batch && (!fast || have_fast)) return PT_OK;
-    if (batch < ws.batch && ws.size == size) batch = ws.batch;
-    fast = fast || (have_fast && ws.size == size);
+    if (ws.size == size && ws.batch >= batch && (!fast || have_fast) && ws.nsub >= nsub) return PT_OK;
+    if (ws.size == size) {
+        if (batch < ws.batch) batch = ws.batch;
+        if (nsub < ws.nsub) nsub = ws.nsub;
+        fast = fast || have_fast;
+    }
     ws_release(ws);
     size_t P = (size_t)size * size;
     FrameBuffers &F = ws.F;
@@ -288,9 +292,14 @@ int ensure_workspace(PtScene *sc, int size, int batch, bool fast) {
     WS(ws_alloc(ws, P * 3, &F.rgb));
     WS(ws_alloc(ws, P * 3, &F.bgr));
     WS(ws_alloc(ws, (size_t)RC_N, &F.counters));
+    WS(ws_alloc(ws, P * nsub * 3, &ws.B.paint));
+    WS(ws_alloc(ws, P * nsub * 9, &ws.B.g));
+    WS(ws_alloc(ws, P * nsub, &ws.B.found));
+    WS(ws_alloc(ws, P * nsub, &ws.B.tri));
+    WS(ws_alloc(ws, P * nsub * 3, &ws.B.tuv));
     if (fast) WS(fast_alloc(ws.Q, P, batch, ws_alloc_cb, &ws));
 #undef WS
-    ws.size = size; ws.batch = batch;
+    ws.size = size; ws.batch = batch; ws.nsub = nsub;
     return PT_OK;
 }
 
@@ -323,7 +332,7 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
         if (batch < 1) batch = 1;
         if (batch > N) batch = N;
     }
-    rc = ensure_workspace(sc, size, batch, fast);
+    rc = ensure_workspace(sc, size, batch, fast, o->rb ? 9 : 1);
     if (rc) return rc;
     FrameBuffers &F = sc->ws.F;
     ViewParams V{};
@@ -336,7 +345,7 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     V.seed = o->seed; V.view = o->view; V.model = o->model;
     hipStream_t s = sc->stream;
     HIPCHK(hipMemsetAsync(F.counters, 0, RC_N * sizeof(unsigned long long), s));
-    if (exact_primary(sc->S, V, F, s)) return fail(PT_ERR_HIP, "primary pass launch failed");
+    if (exact_primary(sc->S, V, F, sc->ws.B, s)) return fail(PT_ERR_HIP, "primary pass launch failed");
     *gi_ms = 0; *gi_launches = 0;
     uint64_t fast_rays = 0, fast_shadow = 0, fast_work[2] = {0, 0};
     const bool count_work = fast && (o->flags & PT_FLAG_COUNT_WORK);

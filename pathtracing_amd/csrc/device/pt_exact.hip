@@ -29,40 +29,75 @@ PT_DEV void flush_counts(const RayCounts &rc, unsigned long long *counters) {
     }
 }
 
+// Primary pass, one thread per sub-ray.  Without -rb a wave is one 8x8 pixel tile.  With
+// -rb every sub-ray of a bundle is its own thread and the nine sub-rays of a pixel sit in
+// adjacent lanes (7 pixels x 9 = 63 lanes of a wave, one lane idle): they differ by a
+// hundredth of a pixel, so they walk the tree together.  The sub-ray results are folded
+// into the frame buffers by k_primary_combine in the reference's order.
 template <int MODEL>
-__global__ void __launch_bounds__(64) k_primary_exact(DevScene S, ViewParams V, FrameBuffers F) {
-    int i, j;
+__global__ void __launch_bounds__(64) k_primary_exact(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B) {
     RayCounts rc;
 #pragma unroll
     for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
-    bool live = tile_pixel(blockIdx.x * 64 + threadIdx.x, V.size, i, j);
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t lin;
+    int sub = 4;
+    bool live = true;
+    if (V.rb) {
+        const uint32_t item = blockIdx.x * 63u + lane;
+        lin = item / 9u;
+        sub = (int)(item - lin * 9u);
+        live = lane < 63u;
+    } else {
+        lin = blockIdx.x * 64u + lane;
+    }
+    int i = 0, j = 0;
+    live = live && tile_pixel((int)lin, V.size, i, j);
     if (live) {
-        size_t p = (size_t)i * V.size + j;
-        D3 src = d3(V.eye[0], V.eye[1], V.eye[2]);
-        D3 paint = d3(0, 0, 0);
+        const size_t p = (size_t)i * V.size + j, slot = V.rb ? p * 9 + sub : p;
+        // the offsets as the reference's loops produce them: -o, -o + o, (-o + o) + o  (main.cpp:116-117)
+        const double o0 = -V.off, o1 = o0 + V.off, o2 = o1 + V.off;
+        const int xi = sub % 3, yi = sub / 3;
+        const double x = xi == 0 ? o0 : (xi == 1 ? o1 : o2), y = yi == 0 ? o0 : (yi == 1 ? o1 : o2);
+        RayD ray = camera_ray(d3(V.eye[0], V.eye[1], V.eye[2]), V.zoom, V.sa, V.ca, V.size, i, j, x, y);
         GBufD g;
         g.clr = d3(0, 0, 0); g.nrm = d3(0, 0, 0); g.hit = d3(0, 0, 0);
         PrimRec rec; rec.found = 0; rec.tri = -1; rec.t = -1; rec.u = 0; rec.v = 0;
-        const double off = V.off;
-        for (double y = -off; y <= off; y += off)
-            for (double x = -off; x <= off; x += off) {
-                if (!V.rb && (x != 0 || y != 0)) continue;
-                RayD ray = camera_ray(src, V.zoom, V.sa, V.ca, V.size, i, j, x, y);
-                // MAIN: every sub-ray writes the pixel's G-buffer, the last one wins (main.cpp:68-70);
-                // OMP: only the centre ray does (mainOMP.cpp:124-127).
-                bool owner = (MODEL == PT_MODEL_MAIN) || (x == 0 && y == 0);
-                GBufD scratch;
-                PrimRec rscr;
-                rc.n[RC_PRIMARY]++;
-                paint = dadd(paint, cast_ray<MODEL, true>(S, ray, 0, owner ? &g : &scratch, owner ? &rec : &rscr, rc));
-            }
-        if (V.rb) paint = ddivs(paint, 9.0);
-        dstore(F.mpnt + 3 * p, paint);
-        dstore(F.gclr + 3 * p, g.clr); dstore(F.gnrm + 3 * p, g.nrm); dstore(F.ghit + 3 * p, g.hit);
-        F.rec_found[p] = rec.found; F.rec_tri[p] = rec.found ? rec.tri : -1;
-        F.rec_t[p] = rec.found ? rec.t : -1.0; F.rec_u[p] = rec.u; F.rec_v[p] = rec.v;
+        rc.n[RC_PRIMARY]++;
+        D3 paint = cast_ray<MODEL, true>(S, ray, 0, &g, &rec, rc);
+        dstore(B.paint + 3 * slot, paint);
+        dstore(B.g + 9 * slot, g.clr); dstore(B.g + 9 * slot + 3, g.nrm); dstore(B.g + 9 * slot + 6, g.hit);
+        B.found[slot] = rec.found; B.tri[slot] = rec.found ? rec.tri : -1;
+        B.tuv[3 * slot] = rec.found ? rec.t : -1.0; B.tuv[3 * slot + 1] = rec.u; B.tuv[3 * slot + 2] = rec.v;
     }
     flush_counts(rc, F.counters);
+}
+
+// Sum of the sub-rays in the reference's order, /9 for a bundle (main.cpp:122-125).  G-buffer owner:
+// MAIN -- every sub-ray writes, the last wins, a miss only writes mhit (main.cpp:44-47,68-70);
+// OMP -- the centre ray only (mainOMP.cpp:124-127).
+template <int MODEL>
+__global__ void k_primary_combine(FrameBuffers F, SubBuffers B, int size, int rb) {
+    size_t P = (size_t)size * size, p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int nsub = rb ? 9 : 1;
+    D3 paint = d3(0, 0, 0), clr = d3(0, 0, 0), nrm = d3(0, 0, 0), hit = d3(0, 0, 0);
+    size_t owner = p * nsub;
+    for (int s = 0; s < nsub; s++) {
+        size_t k = p * nsub + s;
+        paint = dadd(paint, dload(B.paint + 3 * k));
+        bool writes = MODEL == PT_MODEL_MAIN || !rb || s == 4;
+        if (writes) {
+            owner = k;
+            if (B.found[k]) { clr = dload(B.g + 9 * k); nrm = dload(B.g + 9 * k + 3); }
+            hit = dload(B.g + 9 * k + 6);
+        }
+    }
+    if (rb) paint = ddivs(paint, 9.0);
+    dstore(F.mpnt + 3 * p, paint);
+    dstore(F.gclr + 3 * p, clr); dstore(F.gnrm + 3 * p, nrm); dstore(F.ghit + 3 * p, hit);
+    F.rec_found[p] = B.found[owner]; F.rec_tri[p] = B.tri[owner];
+    F.rec_t[p] = B.tuv[3 * owner]; F.rec_u[p] = B.tuv[3 * owner + 1]; F.rec_v[p] = B.tuv[3 * owner + 2];
 }
 
 // globalIllumination, main.cpp:85-101 / mainOMP.cpp:85-101, one sample per thread.
@@ -154,12 +189,17 @@ __global__ void k_hemisphere(uint32_t seed, uint32_t view, uint32_t pixel, int n
 // ---- host-side launchers ----------------------------------------------------------
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? PT_OK : PT_ERR_HIP)
 
-int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, hipStream_t s) {
-    int blocks = tile_threads(V.size) / 64;
-    if (V.model == PT_MODEL_MAIN)
-        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_MAIN>, dim3(blocks), dim3(64), 0, s, S, V, F);
-    else
-        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_OMP>, dim3(blocks), dim3(64), 0, s, S, V, F);
+int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const SubBuffers &B, hipStream_t s) {
+    const size_t P = (size_t)V.size * V.size;
+    const unsigned cblocks = (unsigned)((P + 255) / 256);
+    const unsigned blocks = V.rb ? (unsigned)(((size_t)tile_threads(V.size) * 9 + 62) / 63) : (unsigned)(tile_threads(V.size) / 64);
+    if (V.model == PT_MODEL_MAIN) {
+        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_MAIN>, dim3(blocks), dim3(64), 0, s, S, V, F, B);
+        hipLaunchKernelGGL(k_primary_combine<PT_MODEL_MAIN>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb);
+    } else {
+        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_OMP>, dim3(blocks), dim3(64), 0, s, S, V, F, B);
+        hipLaunchKernelGGL(k_primary_combine<PT_MODEL_OMP>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb);
+    }
     return LAUNCH_OK();
 }
 

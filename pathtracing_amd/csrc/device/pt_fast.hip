@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "pt_frame.h"
+#include "pt_persistent.h"
 #include "pt_trace_f32.h"
 #include "pt_vec.h"
 
@@ -25,68 +26,6 @@
 #define PT_REFILL_MIN 8             // idle lanes that trigger a refill
 #define PT_QUEUE_CHUNK 128          // work items a wave takes from the queue head per atomicAdd (upper bound)
 #define PT_TRACE_WAVES (256 * 32)   // enough waves to fill every CU; surplus waves find the queue empty
-
-// ---- the persistent loop ---------------------------------------------------------------
-// Work items 0 .. n_items-1 are drawn from *head in chunks (one atomicAdd per chunk
-// per wave, so the head word is touched once per `chunk` items, not once per refill).
-// Policy::start(item, L, box) fetches an item and begins its first ray (false: the
-// item needed no traversal and is complete); Policy::finish(L, box) consumes a
-// finished ray and either begins another ray of the same item (true) or completes
-// the item (false).  A wave leaves when the queue is drained and all of its lanes
-// are done, so the grid always drains.
-template <bool ANY, bool COUNT, class Policy>
-__device__ __forceinline__ void persistent_trace(const DevScene &S, Policy &P, uint32_t n_items, uint32_t *head, uint32_t chunk,
-                                                 int refill_min, uint32_t slot_mask, uint2 *stack,
-                                                 unsigned long long *work_out) {
-    const uint32_t lane = threadIdx.x & 63;
-    uint2 *stk = stack + lane;
-    const RootBox box = root_box(S);
-    LaneState L;
-    L.toff = L.tend = 0; L.nlink = 0xFFFFFFFFu; L.nsplit = 0;
-    bool active = false, more = true;
-    uint32_t chunk_next = 0, chunk_end = 0;
-    uint32_t work[2] = {0, 0};
-    for (;;) {
-        const unsigned long long idle = __ballot(!active);
-        if (more && __popcll(idle) >= refill_min) {
-            if (chunk_next == chunk_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(head, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                chunk_next = base < n_items ? base : n_items;
-                chunk_end = base + chunk < n_items ? base + chunk : n_items;
-                if (chunk_next == chunk_end) more = false;
-            }
-            const uint32_t want = (uint32_t)__popcll(idle), have = chunk_end - chunk_next;
-            const uint32_t take = want < have ? want : have, base = chunk_next;
-            chunk_next += take;
-            if (!active) {
-                const uint32_t k = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (k < take) {
-                    active = P.start(base + k, L, box);
-                    if (COUNT && active) { work[0]++; work[1] += (L.tend - L.toff) / 48u; }
-                }
-            }
-        }
-        if (!__any(active)) {
-            if (!more) break;
-            continue;
-        }
-        if (active) {
-            if (lane_turn<ANY, COUNT>(L, S, stk, slot_mask, work)) {
-                active = P.finish(L, box);
-                if (COUNT && active) { work[0]++; work[1] += (L.tend - L.toff) / 48u; }
-            }
-        }
-    }
-    if (COUNT) {
-        for (int k = 0; k < 2; k++) {
-            uint32_t v = work[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) atomicAdd(&work_out[k], (unsigned long long)v);
-        }
-    }
-}
 
 // Queue append for a whole workgroup: ballot + prefix popcount inside each wave, a
 // scan over the block's waves in LDS, ONE atomicAdd per block.  (One atomicAdd per
@@ -164,19 +103,26 @@ __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_gi_gen(ViewParams V, FrameB
 }
 
 // ---- stage 2: closest hit -------------------------------------------------------
+template <bool COUNT>
 struct ClosestPolicy {
     const DevScene &S;
     const FastBuffers &Q;
-    uint32_t r;
-    __device__ __forceinline__ bool start(uint32_t item, LaneState &L, const RootBox &box) {
-        r = item;
-        const float4 o = Q.rays_o[r], d = Q.rays_d[r];
-        if (lane_begin(L, S, box, o.x, o.y, o.z, d.x, d.y, d.z, FLT_MAX, __float_as_int(o.w))) return true;
-        Q.hits[r] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    const RootBox box;
+    uint2 *stk;
+    uint32_t slot_mask;
+    LaneState L;
+    uint32_t r, work[2];
+    __device__ __forceinline__ void census() { if (COUNT) { work[0]++; work[1] += (L.tend - L.toff) / 48u; } }
+    __device__ __forceinline__ bool turn() {
+        if (!lane_turn<false, COUNT>(L, S, stk, slot_mask, work)) return true;
+        Q.hits[r] = make_float4(L.tmin, L.hu, L.hv, __int_as_float(L.htri));
         return false;
     }
-    __device__ __forceinline__ bool finish(LaneState &L, const RootBox &) {
-        Q.hits[r] = make_float4(L.tmin, L.hu, L.hv, __int_as_float(L.htri));
+    __device__ __forceinline__ bool start(uint32_t item) {
+        r = item;
+        const float4 o = Q.rays_o[r], d = Q.rays_d[r];
+        if (lane_begin(L, S, box, o.x, o.y, o.z, d.x, d.y, d.z, FLT_MAX, __float_as_int(o.w))) { census(); return true; }
+        Q.hits[r] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         return false;
     }
 };
@@ -184,8 +130,16 @@ struct ClosestPolicy {
 template <bool COUNT>
 __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
     extern __shared__ uint2 stack[];            // (slot_mask + 1) * 64 entries
-    ClosestPolicy P{S, Q, 0};
-    persistent_trace<false, COUNT>(S, P, Q.counts[0], &Q.counts[3], chunk, refill_min, slot_mask, stack, Q.work);
+    ClosestPolicy<COUNT> P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
+    P.work[0] = P.work[1] = 0;
+    persistent_loop(P, Q.counts[0], &Q.counts[3], chunk, refill_min);
+    if (COUNT) {
+        for (int k = 0; k < 2; k++) {
+            uint32_t v = P.work[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&Q.work[k], (unsigned long long)v);
+        }
+    }
 }
 
 // ---- stage 3: shading of the GI hits ---------------------------------------------
@@ -308,12 +262,16 @@ __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBu
 struct ShadowPolicy {
     const DevScene &S;
     const FastBuffers &Q;
+    const RootBox box;
+    uint2 *stk;
+    uint32_t slot_mask;
+    LaneState L;
     float px, py, pz, nx, ny, nz, br, bg, bb, dr, dg, db, c, sr, sg, sb;
     int tri, k;
     uint32_t slot, shadow;
     // Find the next light in front of the surface and begin its shadow ray; complete the
     // point when there is none (a light behind the surface adds 0 whatever its ray says).
-    __device__ __forceinline__ bool next_light(LaneState &L, const RootBox &box) {
+    __device__ __forceinline__ bool next_light() {
         for (; k < S.n_light; k++) {
             float lx, ly, lz, dis;
             light_f(S.lights[k], px, py, pz, lx, ly, lz, dis, sr, sg, sb);
@@ -327,26 +285,27 @@ struct ShadowPolicy {
         Q.contrib[slot] = make_float4(br * dr, bg * dg, bb * db, 0.f);
         return false;
     }
-    __device__ __forceinline__ bool start(uint32_t item, LaneState &L, const RootBox &box) {
+    __device__ __forceinline__ bool start(uint32_t item) {
         const float4 pos = Q.sp_pos[item], nrm = Q.sp_nrm[item], base = Q.sp_base[item];
         px = pos.x; py = pos.y; pz = pos.z; tri = __float_as_int(pos.w);
         nx = nrm.x; ny = nrm.y; nz = nrm.z; slot = __float_as_uint(nrm.w);
         br = base.x; bg = base.y; bb = base.z;
         dr = dg = db = 0.f; k = 0;
-        return next_light(L, box);
+        return next_light();
     }
-    __device__ __forceinline__ bool finish(LaneState &L, const RootBox &box) {
+    __device__ __forceinline__ bool turn() {
+        if (!lane_turn<true, false>(L, S, stk, slot_mask, nullptr)) return true;
         if (L.htri < 0) { dr += c * sr; dg += c * sg; db += c * sb; }
         k++;
-        return next_light(L, box);
+        return next_light();
     }
 };
 
 __global__ void __launch_bounds__(64) k_shadow_gi(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
     extern __shared__ uint2 stack[];
-    ShadowPolicy P{S, Q};
+    ShadowPolicy P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
     P.shadow = 0;
-    persistent_trace<true, false>(S, P, Q.counts[1], &Q.counts[4], chunk, refill_min, slot_mask, stack, nullptr);
+    persistent_loop(P, Q.counts[1], &Q.counts[4], chunk, refill_min);
     uint32_t n = P.shadow;
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(&Q.counts[2], n);
@@ -368,12 +327,16 @@ __global__ void k_gi_sum(FrameBuffers F, FastBuffers Q, int size, int nb, int fi
 // ---- raw queries for tests: fp64 in/out around the fp32 traversal -------------------
 struct RawPolicy {
     const DevScene &S;
+    const RootBox box;
+    uint2 *stk;
+    uint32_t slot_mask;
+    LaneState L;
     const double *src, *dir, *tmin_in;
     int32_t *found, *tri;
     double *t, *u, *v;
     size_t k;
     __device__ __forceinline__ void miss() { found[k] = 0; tri[k] = -1; t[k] = tmin_in[k]; u[k] = 0; v[k] = 0; }
-    __device__ __forceinline__ bool start(uint32_t item, LaneState &L, const RootBox &box) {
+    __device__ __forceinline__ bool start(uint32_t item) {
         k = item;
         double tm = tmin_in[k];
         float tmax = tm >= (double)FLT_MAX ? FLT_MAX : (float)tm;
@@ -383,7 +346,8 @@ struct RawPolicy {
         miss();
         return false;
     }
-    __device__ __forceinline__ bool finish(LaneState &L, const RootBox &) {
+    __device__ __forceinline__ bool turn() {
+        if (!lane_turn<false, false>(L, S, stk, slot_mask, nullptr)) return true;
         if (L.htri < 0) { miss(); return false; }
         found[k] = 1; tri[k] = L.htri; t[k] = (double)L.tmin; u[k] = (double)L.hu; v[k] = (double)L.hv;
         return false;
@@ -394,8 +358,8 @@ __global__ void __launch_bounds__(64) k_trace_fast_f64io(DevScene S, uint32_t n,
                                                          const double *tmin_in, int32_t *found, int32_t *tri, double *t,
                                                          double *u, double *v, uint32_t slot_mask) {
     extern __shared__ uint2 stack[];
-    RawPolicy P{S, src, dir, tmin_in, found, tri, t, u, v, 0};
-    persistent_trace<false, false>(S, P, n, head, 64u, 1, slot_mask, stack, nullptr);
+    RawPolicy P{S, root_box(S), stack + (threadIdx.x & 63), slot_mask, LaneState(), src, dir, tmin_in, found, tri, t, u, v, 0};
+    persistent_loop(P, n, head, 64u, 1);
 }
 
 // ---- host side ------------------------------------------------------------------------

@@ -30,6 +30,15 @@ struct FrameBuffers {
 };
 
 
+// Outputs of the primary pass per sub-ray (one sub-ray without -rb, nine with); the combine
+// kernel folds them into the frame buffers in the reference's order.  Index = pixel * nsub + sub.
+struct SubBuffers {
+    double *paint;             // 3: castRay's value
+    double *g;                 // 9: mclr, mnrm, mhit candidate
+    int32_t *found, *tri;
+    double *tuv;               // 3: t, u, v
+};
+
 // Queues and slots of the fp32 GI wavefront path (pt_fast.hip).
 struct FastBuffers {
     float4 *rays_o;           // origin xyz, index bits of the triangle the ray starts on (never reported as a hit)
@@ -49,7 +58,7 @@ struct FastBuffers {
 static inline int tile_threads(int size) { int t = (size + 7) >> 3; return t * t * 64; }
 
 // ---- pt_exact.hip ----
-int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, hipStream_t s);
+int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const SubBuffers &B, hipStream_t s);
 int exact_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, int s0, int nb, hipStream_t s);
 int gi_accumulate(const FrameBuffers &F, int size, int nb, int first_batch, hipStream_t s);
 int resolve_frame(const FrameBuffers &F, int size, int gi, int nsamples, hipStream_t s);
