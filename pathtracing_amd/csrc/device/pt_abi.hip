@@ -250,6 +250,15 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     UP(dev_copy(sc, trows.data(), trows.size(), &S.tex_rows));
     UP(dev_copy(sc, tcols.data(), tcols.size(), &S.tex_cols));
     UP(dev_copy(sc, d->lights, (size_t)d->n_light, &S.lights));
+    {
+        std::vector<float4> lf(2 * (size_t)d->n_light);
+        for (uint32_t k = 0; k < d->n_light; k++) {
+            const PtLight &L = d->lights[k];
+            lf[2 * k] = make_float4((float)L.pos[0], (float)L.pos[1], (float)L.pos[2], bits_to_float(L.type));
+            lf[2 * k + 1] = make_float4((float)(L.mag * L.color[0]), (float)(L.mag * L.color[1]), (float)(L.mag * L.color[2]), 0.f);
+        }
+        UP(dev_copy(sc, lf.data(), lf.size(), &S.lightsF));
+    }
 #undef UP
     S.n_light = (int32_t)d->n_light; S.n_node = (int32_t)d->n_node; S.n_ref = (int32_t)d->n_ref; S.n_tri = (int32_t)d->n_tri;
     for (int k = 0; k < 3; k++) {

@@ -194,21 +194,23 @@ __device__ __forceinline__ SurfF surface_f(const DevScene &S, int tri, float bu,
 }
 
 // Light::illuminate (util/lighting.cpp:24-36) in fp32: direction, distance, radiance.
-__device__ __forceinline__ void light_f(const PtLight &L, float hx, float hy, float hz, float &lx, float &ly, float &lz,
+// Lights come as two float4 each: (position, type) and (mag * colour, 0).
+__device__ __forceinline__ void light_f(const float4 *lights, int k, float hx, float hy, float hz, float &lx, float &ly, float &lz,
                                         float &dis, float &sr, float &sg, float &sb) {
-    float px = (float)L.pos[0], py = (float)L.pos[1], pz = (float)L.pos[2], mag = (float)L.mag;
-    if (L.type == 'd') {
-        float il = 1.0f / sqrtf(px * px + py * py + pz * pz);
-        lx = px * il; ly = py * il; lz = pz * il;
+    const float4 a = lights[2 * k], b = lights[2 * k + 1];
+    if (__float_as_int(a.w) == 'd') {
+        float il = __builtin_amdgcn_rsqf(a.x * a.x + a.y * a.y + a.z * a.z);
+        lx = a.x * il; ly = a.y * il; lz = a.z * il;
         dis = FLT_MAX;
-        sr = mag * (float)L.color[0]; sg = mag * (float)L.color[1]; sb = mag * (float)L.color[2];
+        sr = b.x; sg = b.y; sb = b.z;
     } else {
-        lx = px - hx; ly = py - hy; lz = pz - hz;
-        dis = sqrtf(lx * lx + ly * ly + lz * lz);
-        float il = 1.0f / dis;
+        lx = a.x - hx; ly = a.y - hy; lz = a.z - hz;
+        float d2 = lx * lx + ly * ly + lz * lz;
+        float il = __builtin_amdgcn_rsqf(d2);
+        dis = d2 * il;
         lx *= il; ly *= il; lz *= il;
-        float k = mag / (4.0f * dis * 3.14159265358979f);
-        sr = k * (float)L.color[0]; sg = k * (float)L.color[1]; sb = k * (float)L.color[2];
+        float k4 = il * (1.0f / (4.0f * 3.14159265358979f));          // 1 / (4 * dis * pi): linear falloff
+        sr = k4 * b.x; sg = k4 * b.y; sb = k4 * b.z;
     }
 }
 
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBu
                 float dr = 0, dg = 0, db = 0;
                 for (int k = 0; k < S.n_light; k++) {
                     float lx, ly, lz, dis, sr, sg, sb;
-                    light_f(S.lights[k], hx, hy, hz, lx, ly, lz, dis, sr, sg, sb);
+                    light_f(S.lightsF, k, hx, hy, hz, lx, ly, lz, dis, sr, sg, sb);
                     float c = fmaxf(0.0f, lx * sf.nx + ly * sf.ny + lz * sf.nz);
                     dr += c * sr; dg += c * sg; db += c * sb;
                 }
@@ -266,45 +268,56 @@ struct ShadowPolicy {
     uint2 *stk;
     uint32_t slot_mask;
     LaneState L;
-    float px, py, pz, nx, ny, nz, br, bg, bb, dr, dg, db, c, sr, sg, sb;
-    int tri, k;
-    uint32_t slot, shadow;
-    // Find the next light in front of the surface and begin its shadow ray; complete the
-    // point when there is none (a light behind the surface adds 0 whatever its ray says).
-    __device__ __forceinline__ bool next_light() {
+    // Little is kept per lane: the point is the origin of the running ray (L.ox..), its triangle is
+    // L.skip, and the normal / base colour are re-read from the queue when a light is chosen or the
+    // point completes.
+    float pr, pg, pb;           // cos * radiance of the light whose ray is running
+    float dr, dg, db;           // sum over the visible lights so far
+    uint32_t item, shadow;
+    int k;
+    bool fresh;
+    __device__ __forceinline__ bool start(uint32_t it) {
+        item = it;
+        const float4 pos = Q.sp_pos[item];
+        L.ox = pos.x; L.oy = pos.y; L.oz = pos.z; L.skip = __float_as_int(pos.w);
+        dr = dg = db = 0.f; k = 0;
+        fresh = true;               // the first turn only picks the first light (keeps one copy of that code)
+        return true;
+    }
+    // A turn: one unit of the running shadow ray; when it ends (or the point is new), find the
+    // next light in front of the surface and begin its ray, or complete the point when there
+    // is none (a light behind the surface adds 0 whatever its ray says).
+    __device__ __forceinline__ bool turn() {
+        if (!fresh) {
+            if (!lane_turn<true, false>(L, S, stk, slot_mask, nullptr)) return true;
+            if (L.htri < 0) { dr += pr; dg += pg; db += pb; }
+            k++;
+        }
+        fresh = false;
+        const float4 nrm = Q.sp_nrm[item];
+        const float px = L.ox, py = L.oy, pz = L.oz;
+        const int tri = L.skip;
         for (; k < S.n_light; k++) {
-            float lx, ly, lz, dis;
-            light_f(S.lights[k], px, py, pz, lx, ly, lz, dis, sr, sg, sb);
-            c = lx * nx + ly * ny + lz * nz;
+            float lx, ly, lz, dis, sr, sg, sb;
+            light_f(S.lightsF, k, px, py, pz, lx, ly, lz, dis, sr, sg, sb);
+            const float c = lx * nrm.x + ly * nrm.y + lz * nrm.z;
             if (c > 0.0f) {
                 shadow++;
+                pr = c * sr; pg = c * sg; pb = c * sb;
                 if (lane_begin(L, S, box, px, py, pz, lx, ly, lz, dis, tri)) return true;
-                dr += c * sr; dg += c * sg; db += c * sb;             // ray misses the scene box: visible
+                dr += pr; dg += pg; db += pb;                         // ray misses the scene box: visible
             }
         }
-        Q.contrib[slot] = make_float4(br * dr, bg * dg, bb * db, 0.f);
+        const float4 base = Q.sp_base[item];
+        Q.contrib[__float_as_uint(nrm.w)] = make_float4(base.x * dr, base.y * dg, base.z * db, 0.f);
         return false;
-    }
-    __device__ __forceinline__ bool start(uint32_t item) {
-        const float4 pos = Q.sp_pos[item], nrm = Q.sp_nrm[item], base = Q.sp_base[item];
-        px = pos.x; py = pos.y; pz = pos.z; tri = __float_as_int(pos.w);
-        nx = nrm.x; ny = nrm.y; nz = nrm.z; slot = __float_as_uint(nrm.w);
-        br = base.x; bg = base.y; bb = base.z;
-        dr = dg = db = 0.f; k = 0;
-        return next_light();
-    }
-    __device__ __forceinline__ bool turn() {
-        if (!lane_turn<true, false>(L, S, stk, slot_mask, nullptr)) return true;
-        if (L.htri < 0) { dr += c * sr; dg += c * sg; db += c * sb; }
-        k++;
-        return next_light();
     }
 };
 
 __global__ void __launch_bounds__(64) k_shadow_gi(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
     extern __shared__ uint2 stack[];
     ShadowPolicy P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
-    P.shadow = 0;
+    P.shadow = 0; P.fresh = false;
     persistent_loop(P, Q.counts[1], &Q.counts[4], chunk, refill_min);
     uint32_t n = P.shadow;
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);

@@ -51,6 +51,7 @@ struct DevScene {
     const int64_t *tex_off;
     const int32_t *tex_rows, *tex_cols;
     const PtLight *lights;
+    const float4 *lightsF;     // fp32 lights, two float4 each: (position, type), (mag * colour, 0)
     int32_t n_light, n_node, n_ref, n_tri;
     double bg[3];
     double root_lo[3], root_hi[3];

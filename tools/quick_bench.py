@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Run bench.py for a few workloads and print the key numbers (development aid)."""
 import json
+import os
 import subprocess
 import sys
 
 args = sys.argv[1:] or ["car", "atrium"]
 for w in args:
     out = subprocess.run([sys.executable, "bench.py", "--workload", w, "--steps", "3", "--warmup", "1", "--spp", "64",
-                          "--no-cpu-baseline"], capture_output=True, text=True)
+                          "--no-cpu-baseline"] + os.environ.get("QB_ARGS", "").split(), capture_output=True, text=True)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(w, "FAILED", out.stdout[-2000:], out.stderr[-2000:])
