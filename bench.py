@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--model", default="omp", choices=["main", "omp"])
     ap.add_argument("--rb", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 path with every rank on GPU 0 and the exchanges staged through host memory")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     a = ap.parse_args()
 
@@ -115,11 +117,16 @@ def main():
     from pathtracing_amd import device, multiview
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gpu = local_rank if a.backend == "nccl" else 0
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    xdev = dev if a.backend == "nccl" else torch.device("cpu")     # where the exchanged tensors live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-    device.init(local_rank)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    device.init(gpu)
     model = device.MODEL_OMP if a.model == "omp" else device.MODEL_MAIN
 
     # ---- scene: read + kd build on rank 0, RCCL broadcast of the packed blob ----
@@ -130,8 +137,8 @@ def main():
         blob = device.scene_blob(hs.desc())
         cams = np.array([[*v.eye, v.angle, v.zoom] for v in views])
     if world > 1:
-        blob = multiview.broadcast_bytes(blob if rank == 0 else None, dev, dist)   # the scene + kd-tree travel over xGMI once
-        cams = multiview.broadcast_cameras(cams if rank == 0 else None, dev, dist)
+        blob = multiview.broadcast_bytes(blob if rank == 0 else None, xdev, dist)   # the scene + kd-tree travel over xGMI once
+        cams = multiview.broadcast_cameras(cams if rank == 0 else None, xdev, dist)
     ds = device.DeviceScene(blob=blob)
     scene_seconds = time.time() - t_scene
     views = [device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])) for c in cams]
@@ -140,13 +147,13 @@ def main():
     size = 512
     opt = dict(gi=True, rb=a.rb, model=model, spp=a.spp, gi_precision=device.GI_F32_FAST, size=size)
     frame = torch.empty(size * size * 3, dtype=torch.uint8, device=dev)
-    gather = multiview.FrameGather(frame.numel(), dev, dist) if world > 1 else None
+    gather = multiview.FrameGather(frame.numel(), xdev, dist) if world > 1 else None
 
     def step(i, stats):
         v = (i * world + rank) % nviews
         ds.render_to_device(views[v], frame.data_ptr(), stats=stats, view=v, **opt)
         if world > 1:
-            gather.gather(frame, i, nviews)       # finished frames go to rank 0
+            gather.gather(frame if a.backend == "nccl" else frame.cpu(), i, nviews)       # finished frames go to rank 0
 
     def sync():
         if world > 1:
@@ -165,7 +172,7 @@ def main():
     dt = time.perf_counter() - t0
 
     rays_local = stats.primary + stats.shadow + stats.mirror + stats.gi
-    agg = torch.tensor([dt, float(rays_local), float(stats.gi)], dtype=torch.float64, device=dev)
+    agg = torch.tensor([dt, float(rays_local), float(stats.gi)], dtype=torch.float64, device=xdev)
     if world > 1:
         tmax = agg[0:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

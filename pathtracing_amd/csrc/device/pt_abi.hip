@@ -204,6 +204,17 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     };
     for (uint32_t r = 0; r < d->n_ref; r++) tri9(d->refs[r], &rt[(size_t)r * 9]);
     for (NodeF &n : nf) n = encode_node(n);
+    // ---- per-triangle geometry by triangle index (origin-triangle tests of the GI fast path) ----
+    std::vector<double> tgeo((size_t)d->n_tri * 9);
+    std::vector<float4> tng(d->n_tri);
+    for (uint32_t t = 0; t < d->n_tri; t++) {
+        double *o = &tgeo[(size_t)t * 9];
+        tri9((int32_t)t, o);
+        double nx = o[4] * o[8] - o[5] * o[7], ny = o[5] * o[6] - o[3] * o[8], nz = o[3] * o[7] - o[4] * o[6];
+        double l = std::sqrt(nx * nx + ny * ny + nz * nz);
+        l = l > 0 ? 1.0 / l : 0.0;
+        tng[t] = make_float4((float)(nx * l), (float)(ny * l), (float)(nz * l), 0.f);
+    }
     std::vector<float4> rtf(frefs.size() * 3);
     for (size_t r = 0; r < frefs.size(); r++) {
         double o[9];
@@ -228,6 +239,20 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     UP(dev_copy(sc, nf.data(), nf.size(), &S.nodeF));
     UP(dev_copy(sc, rt.data(), rt.size(), &S.refTri));
     UP(dev_copy(sc, rtf.data(), rtf.size(), &S.refTriF));
+    {
+        // overflow stack of the fp32 traversal: one column of (tree depth + 2) entries per lane of every
+        // wave the trace kernels are launched with
+        S.ovf_depth = (uint32_t)sc->refine.max_depth + 2u;
+        S.ovf_waves = PT_TRACE_WAVES;
+        void *p = nullptr;
+        size_t bytes = (size_t)S.ovf_waves * S.ovf_depth * 64 * sizeof(uint2);
+        if (hipMalloc(&p, bytes) != hipSuccess) return bail(fail(PT_ERR_OOM, "out of device memory (traversal overflow stack)"));
+        sc->owned.push_back(p);
+        sc->dev_bytes += bytes;
+        S.ovf = (uint2 *)p;
+    }
+    UP(dev_copy(sc, tgeo.data(), tgeo.size(), &S.triGeo));
+    UP(dev_copy(sc, tng.data(), tng.size(), &S.triNgF));
     UP(dev_copy(sc, d->refs, (size_t)d->n_ref, &S.refId));
     UP(dev_copy(sc, d->tri_ni, (size_t)d->n_tri * 3, &S.tri_ni));
     UP(dev_copy(sc, d->tri_ti, (size_t)d->n_tri * 3, &S.tri_ti));

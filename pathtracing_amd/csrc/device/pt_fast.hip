@@ -25,7 +25,6 @@
 #define FS_SLOTS 8                  // ring entries per lane in LDS (one of them is kept free)
 #define PT_REFILL_MIN 8             // idle lanes that trigger a refill
 #define PT_QUEUE_CHUNK 128          // work items a wave takes from the queue head per atomicAdd (upper bound)
-#define PT_TRACE_WAVES (256 * 32)   // enough waves to fill every CU; surplus waves find the queue empty
 
 // Queue append for a whole workgroup: ballot + prefix popcount inside each wave, a
 // scan over the block's waves in LDS, ONE atomicAdd per block.  (One atomicAdd per
@@ -74,31 +73,102 @@ __device__ __forceinline__ D3 gi_direction(D3 nrm, uint32_t seed, uint32_t view,
               sm.x * Nb.z + sm.y * nrm.z + sm.z * Nt.z);
 }
 
-__global__ void __launch_bounds__(PT_APPEND_BLOCK) k_gi_gen(ViewParams V, FrameBuffers F, FastBuffers Q, int s0, int tthreads, int nb) {
-    const size_t lin = (size_t)blockIdx.x * PT_APPEND_BLOCK + threadIdx.x;
-    const int sl = (int)(lin / (size_t)tthreads);
-    int i = 0, j = 0;
-    const bool live = sl < nb && tile_pixel_f((int)(lin - (size_t)sl * tthreads), V.size, i, j);
+// The reference starts a GI ray 1e-4 along the SHADING normal from the hit point and tests it against
+// every triangle, the one it starts on included (main.cpp:94-99): where the interpolated normal leans
+// away from the geometric one, sample directions below the triangle's own plane hit that triangle at
+// t ~ 1e-4.  fp32 cannot decide that test (the offset is below one ulp of a coordinate of a few
+// thousand), so the closest-hit kernel skips the origin triangle and this kernel decides it in fp64:
+// Moeller-Trumbore of util/polygonMesh.cpp:54-76 on the one triangle.  Returns t > 0 on a hit.
+__device__ __forceinline__ bool origin_triangle_hit(const double *T9, D3 o, D3 w, float &t, float &u, float &v) {
+    D3 v0 = dload(T9), ba = dload(T9 + 3), ca = dload(T9 + 6);
+    D3 P = dcross(w, ca);
+    double inv = 1.0 / ddot(P, ba);
+    D3 T = dsub(o, v0);
+    double uu = ddot(P, T) * inv;
+    D3 Qv = dcross(T, ba);
+    double vv = ddot(Qv, w) * inv, tt = ddot(Qv, ca) * inv;
+    t = (float)tt; u = (float)uu; v = (float)vv;
+    return uu >= 0.0 && vv >= 0.0 && uu + vv <= 1.0 && tt > 0.0;
+}
+
+// One block = one 8x8 pixel tile x up to 64 samples of the pass (thread = pixel x sample lane,
+// four samples each): 4096 rays with nearby origins.  They are written to the queue sorted by
+// direction bin (counting sort in LDS), so that the 64 rays a wave of the closest-hit kernel
+// draws together start close to each other and point the same way.  Queue order is free: the
+// contribution slot travels with the ray.
+#define PT_GEN_BINS 64
+__device__ __forceinline__ uint32_t dir_bin(float x, float y, float z) {
+    // 4 x 4 x 4 cells of the cube [-1, 1]^3 that contains the unit sphere
+    uint32_t qx = (uint32_t)fminf(fmaxf((x * 0.5f + 0.5f) * 4.0f, 0.0f), 3.0f);
+    uint32_t qy = (uint32_t)fminf(fmaxf((y * 0.5f + 0.5f) * 4.0f, 0.0f), 3.0f);
+    uint32_t qz = (uint32_t)fminf(fmaxf((z * 0.5f + 0.5f) * 4.0f, 0.0f), 3.0f);
+    return (qx << 4) | (qy << 2) | qz;
+}
+
+__global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, FrameBuffers F, FastBuffers Q, int s0, int nb, int groups) {
+    __shared__ uint32_t hist[PT_GEN_BINS];
+    __shared__ uint32_t bin_base[PT_GEN_BINS];
+    __shared__ uint32_t block_base;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x / groups, group = blockIdx.x - tile * groups;
+    int i, j;
+    const bool live = tile_pixel_f(tile * 64 + (tid & 63), V.size, i, j);
     const size_t P = (size_t)V.size * V.size, p = live ? (size_t)i * V.size + j : 0;
-    bool valid = false;
-    float4 ro, rd;
+    if (tid < PT_GEN_BINS) hist[tid] = 0;
+    __syncthreads();
+    bool pix_valid = false;
+    float4 ro = make_float4(0.f, 0.f, 0.f, 0.f);
+    D3 nrm = d3(0, 0, 0), hit = d3(0, 0, 0);
+    int otri = -1;
     if (live) {
-        D3 hit = dload(F.ghit + 3 * p);
-        valid = !(hit.x == -99999);
-        if (valid) {
-            double r1;
-            D3 w = gi_direction(dload(F.gnrm + 3 * p), V.seed, V.view, (uint32_t)p, (uint32_t)(s0 + sl), r1);
-            ro = make_float4((float)hit.x, (float)hit.y, (float)hit.z, __int_as_float(F.rec_tri[p]));
-            rd = make_float4((float)w.x, (float)w.y, (float)w.z, (float)r1);
-        } else {
-            Q.contrib[(size_t)sl * P + p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        hit = dload(F.ghit + 3 * p);
+        pix_valid = !(hit.x == -99999);
+        if (pix_valid) {
+            nrm = dload(F.gnrm + 3 * p);
+            otri = F.rec_tri[p];
+            ro = make_float4((float)hit.x, (float)hit.y, (float)hit.z, __int_as_float(otri));
         }
     }
-    const uint32_t r = block_append(valid, &Q.counts[0]);
-    if (valid) {
-        Q.rays_o[r] = ro;
-        Q.rays_d[r] = rd;
-        Q.ray_slot[r] = (uint32_t)((size_t)sl * P + p);
+    float4 rd[4];
+    float st[4], su[4], sv[4];          // origin-triangle hit of the sample, when there is one
+    uint32_t key[4], rank[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int sl = group * 64 + r * 16 + (tid >> 6);
+        key[r] = 0xFFFFFFFFu;
+        if (live && sl < nb) {
+            if (pix_valid) {
+                double r1;
+                D3 w = gi_direction(nrm, V.seed, V.view, (uint32_t)p, (uint32_t)(s0 + sl), r1);
+                rd[r] = make_float4((float)w.x, (float)w.y, (float)w.z, (float)r1);
+                key[r] = dir_bin(rd[r].x, rd[r].y, rd[r].z);
+                // a ray that hits the triangle it starts on is resolved here; the sign of r1 (>= 0) tells
+                // the closest-hit kernel to leave it alone
+                if (otri >= 0 && origin_triangle_hit(S.triGeo + (size_t)otri * 9, hit, w, st[r], su[r], sv[r]))
+                    rd[r].w = __uint_as_float(__float_as_uint(rd[r].w) | 0x80000000u);
+                rank[r] = atomicAdd(&hist[key[r]], 1u);
+            } else {
+                Q.contrib[(size_t)sl * P + p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < PT_GEN_BINS; k++) { bin_base[k] = tot; tot += hist[k]; }
+        block_base = tot ? atomicAdd(&Q.counts[0], tot) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (key[r] != 0xFFFFFFFFu) {
+            const int sl = group * 64 + r * 16 + (tid >> 6);
+            const uint32_t q = block_base + bin_base[key[r]] + rank[r];
+            Q.rays_o[q] = ro;
+            Q.rays_d[q] = rd[r];
+            Q.ray_slot[q] = (uint32_t)((size_t)sl * P + p);
+            if (__float_as_uint(rd[r].w) >> 31) Q.hits[q] = make_float4(st[r], su[r], sv[r], __int_as_float(otri));
+        }
     }
 }
 
@@ -121,6 +191,7 @@ struct ClosestPolicy {
     __device__ __forceinline__ bool start(uint32_t item) {
         r = item;
         const float4 o = Q.rays_o[r], d = Q.rays_d[r];
+        if (__float_as_uint(d.w) >> 31) return false;      // resolved by the generator (hit on its own triangle)
         if (lane_begin(L, S, box, o.x, o.y, o.z, d.x, d.y, d.z, FLT_MAX, __float_as_int(o.w))) { census(); return true; }
         Q.hits[r] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         return false;
@@ -242,11 +313,11 @@ __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBu
                     float c = fmaxf(0.0f, lx * sf.nx + ly * sf.ny + lz * sf.nz);
                     dr += c * sr; dg += c * sg; db += c * sb;
                 }
-                float k = d.w * (1.0f / 3.14159265358979f);
+                float k = fabsf(d.w) * (1.0f / 3.14159265358979f);
                 Q.contrib[slot] = make_float4(k * ar * dr, k * ag * dg, k * ab * db, 0.f);
             } else {
                 hit = true;
-                float k = d.w * 0.6f * (1.0f / 3.14159265358979f);            // main.cpp:77 with ref = 0
+                float k = fabsf(d.w) * 0.6f * (1.0f / 3.14159265358979f);            // main.cpp:77 with ref = 0
                 sp_pos = make_float4(hx, hy, hz, __int_as_float(tri));
                 sp_nrm = make_float4(sf.nx, sf.ny, sf.nz, __uint_as_float(slot));
                 sp_base = make_float4(k * ar, k * ag, k * ab, 0.f);
@@ -297,15 +368,23 @@ struct ShadowPolicy {
         const float4 nrm = Q.sp_nrm[item];
         const float px = L.ox, py = L.oy, pz = L.oz;
         const int tri = L.skip;
+        // The shadow ray starts 1e-4 along the shading normal and the reference tests it against the
+        // triangle it starts on as well (main.cpp:63-66): that triangle shadows the point when the light is
+        // on the other side of its plane than the shading normal.  Decided here by signs; the search skips
+        // the triangle.
         for (; k < S.n_light; k++) {
             float lx, ly, lz, dis, sr, sg, sb;
             light_f(S.lightsF, k, px, py, pz, lx, ly, lz, dis, sr, sg, sb);
             const float c = lx * nrm.x + ly * nrm.y + lz * nrm.z;
             if (c > 0.0f) {
                 shadow++;
-                pr = c * sr; pg = c * sg; pb = c * sb;
-                if (lane_begin(L, S, box, px, py, pz, lx, ly, lz, dis, tri)) return true;
-                dr += pr; dg += pg; db += pb;                         // ray misses the scene box: visible
+                const float4 ng = S.triNgF[tri];
+                const bool self = (lx * ng.x + ly * ng.y + lz * ng.z) * (nrm.x * ng.x + nrm.y * ng.y + nrm.z * ng.z) < 0.0f;
+                if (!self) {
+                    pr = c * sr; pg = c * sg; pb = c * sb;
+                    if (lane_begin(L, S, box, px, py, pz, lx, ly, lz, dis, tri)) return true;
+                    dr += pr; dg += pg; db += pb;                     // ray misses the scene box: visible
+                }
             }
         }
         const float4 base = Q.sp_base[item];
@@ -397,12 +476,12 @@ int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *
 // variables exist for sweeps.
 struct TraceTune { int slots, refill, waves, chunk; };
 static TraceTune trace_tune() {
-    static TraceTune t = [] {
+    TraceTune t = [] {
         TraceTune v{FS_SLOTS, PT_REFILL_MIN, PT_TRACE_WAVES, PT_QUEUE_CHUNK};
-        if (const char *e = getenv("PT_TUNE_SLOTS")) { int k = atoi(e); if (k == 4 || k == 8 || k == 16 || k == 32) v.slots = k; }
+        if (const char *e = getenv("PT_TUNE_SLOTS")) { int k = atoi(e); if (k == 2 || k == 4 || k == 8 || k == 16 || k == 32) v.slots = k; }
         if (const char *e = getenv("PT_TUNE_REFILL")) { int k = atoi(e); if (k >= 1 && k <= 64) v.refill = k; }
         if (const char *e = getenv("PT_TUNE_CHUNK")) { int k = atoi(e); if (k >= 64 && k <= 65536) v.chunk = k; }
-        if (const char *e = getenv("PT_TUNE_WAVES")) { int k = atoi(e); if (k >= 64 && k <= (1 << 20)) v.waves = k; }
+        if (const char *e = getenv("PT_TUNE_WAVES")) { int k = atoi(e); if (k >= 64 && k <= PT_TRACE_WAVES) v.waves = k; }
         return v;
     }();
     return t;
@@ -419,11 +498,13 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
     for (int s0 = 0; s0 < nsamples; s0 += batch) {
         int nb = nsamples - s0 < batch ? nsamples - s0 : batch;
         if ((size_t)nb * P > Q.max_rays) return PT_ERR_LIMIT;
-        unsigned blocks = (unsigned)(((size_t)tthreads * nb + PT_APPEND_BLOCK - 1) / PT_APPEND_BLOCK);
         unsigned sblocks = (unsigned)((P * nb + PT_APPEND_BLOCK - 1) / PT_APPEND_BLOCK);
         unsigned qblocks = (unsigned)((P * nb + 63) / 64);
         FQ(hipMemsetAsync(Q.counts, 0, 8 * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_gi_gen, dim3(blocks), dim3(PT_APPEND_BLOCK), 0, s, V, F, Q, s0, tthreads, nb);
+        {
+            const int groups = (nb + 63) / 64;
+            hipLaunchKernelGGL(k_gi_gen, dim3((unsigned)((tthreads / 64) * groups)), dim3(1024), 0, s, S, V, F, Q, s0, nb, groups);
+        }
         FQ(hipEventRecord(e0, s));
         unsigned tblocks = qblocks < (unsigned)tune.waves ? qblocks : (unsigned)tune.waves;
         size_t lds = (size_t)tune.slots * 64 * sizeof(uint2);

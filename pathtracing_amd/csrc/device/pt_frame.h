@@ -68,6 +68,7 @@ int camera_rays(const ViewParams &V, double x, double y, double *dir, hipStream_
 int hemisphere_samples(uint32_t seed, uint32_t view, uint32_t pixel, int n, double *out, hipStream_t s);
 
 // ---- pt_fast.hip ----
+#define PT_TRACE_WAVES (256 * 32)   // waves of a trace launch: enough to fill every CU; surplus waves find the queue empty
 #define PT_FAST_RAYS_PER_PASS (16u << 20)
 typedef int (*PtAllocFn)(void *ctx, size_t bytes, void **out);
 int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *ctx);

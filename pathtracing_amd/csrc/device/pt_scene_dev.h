@@ -43,6 +43,10 @@ struct DevScene {
     // ---- fp32 fast path ----
     const NodeF *nodeF;
     const float4 *refTriF;     // 3 float4 per ref: (v0, id bits), (e1, 0), (e2, 0)
+    uint2 *ovf;                // traversal overflow stack: [wave][entry][lane], ovf_depth entries per lane, ovf_waves waves
+    uint32_t ovf_depth, ovf_waves;
+    const double *triGeo;      // 9 per triangle (by triangle index): v0, v1 - v0, v2 - v0
+    const float4 *triNgF;      // per triangle: unit geometric normal (e1 x e2), 0
     // ---- shading data ----
     const int32_t *tri_ni, *tri_ti, *tri_tm, *tri_reft, *tri_mesh, *tri_local;
     const double *norm, *uv, *albedo;

@@ -23,9 +23,13 @@
 // when it is reached; segments are visited front to back and the search ends when
 // the next segment starts at or behind the best hit.  The stack holds (far child,
 // far segment end) only -- a popped segment starts where the previous leaf's
-// segment ended -- in a ring of `slots` entries per lane in LDS.  When the ring is
-// full the oldest entry is dropped and, once the ring runs empty, traversal
-// restarts from the root at the current segment start (short stack + restart).
+// segment ended.  Its newest `slots - 1` entries live in a ring per lane in LDS;
+// when the ring is full its oldest entry moves to the lane's column of an overflow
+// stack in device memory and comes back when the ring has run empty, so no entry
+// is ever lost (a deep tree overflows an 8-entry ring on a few percent of the
+// rays).  A ring that dropped entries and restarted from the root instead cannot
+// make progress through cells of zero length along the ray, which have to be
+// visited (see the node step).
 #pragma once
 #include <float.h>
 #include <hip/hip_runtime.h>
@@ -36,9 +40,9 @@
 
 struct LaneState {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz;
-    float tmin, ent, ext, root_ext, hu, hv;
+    float tmin, ent, ext, hu, hv;
     int htri, skip;
-    uint32_t top, cnt, steps, dropped;
+    uint32_t top, cnt, steps, novf;
     float nsplit;                       // current node
     uint32_t nlink, toff, tend;
 };
@@ -70,8 +74,7 @@ __device__ __forceinline__ bool lane_begin(LaneState &L, const DevScene &S, cons
     L.ent = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
     L.ext = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tmax));
     L.tmin = tmax; L.htri = -1; L.hu = 0; L.hv = 0; L.skip = skip;
-    L.root_ext = L.ext;
-    L.top = 0; L.cnt = 0; L.steps = 0; L.dropped = 0;
+    L.top = 0; L.cnt = 0; L.steps = 0; L.novf = 0;
     if (!(L.ent <= L.ext)) return false;
     load_node(L, S, 0);
     return true;
@@ -80,8 +83,13 @@ __device__ __forceinline__ bool lane_begin(LaneState &L, const DevScene &S, cons
 // One unit of work for this lane.  Returns true when the ray is finished
 // (nearest hit in tmin / hu / hv / htri, htri < 0 for a miss; with ANY the first
 // hit found ends the ray).  `stk` points at this lane's column of the LDS ring,
-// entries 64 apart; slot_mask = slots - 1.  One slot is kept free so that the
-// push below can be an unconditional store.
+// entries 64 apart; slot_mask = slots - 1 >= 1.  One slot is kept free so that the
+// push below can be an unconditional store.  `ovf` points at this lane's column
+// of the overflow stack, entries 64 apart.
+__device__ __forceinline__ uint2 *overflow_column(const DevScene &S) {
+    return S.ovf + (size_t)blockIdx.x * S.ovf_depth * 64 + (threadIdx.x & 63);
+}
+
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2 *stk, uint32_t slot_mask, uint32_t *work) {
     if (L.toff < L.tend) {
@@ -110,28 +118,41 @@ __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2
     const float tmid = (L.nsplit - oa) * ia;
     const uint32_t side = oa > L.nsplit ? 16u : 0u;
     const uint32_t nr = left + side, fr = left + 16u - side;
-    const bool near_only = !(tmid < L.ext) | (tmid < 0.0f);     // also when tmid is NaN (ray in the split plane)
-    const bool far_only = !near_only & (tmid <= L.ent);
+    // A plane met exactly at the segment's start or end sends the ray into BOTH children: a cell of
+    // zero length along the ray may be the thin cell that holds an axis-aligned wall or floor
+    // (the tree builder isolates those), and its triangles have to be tested.
+    const bool near_only = !(tmid <= L.ext) | (tmid < 0.0f);    // also when tmid is NaN (ray in the split plane)
+    const bool far_only = !near_only & (tmid < L.ent);
     const bool both = !near_only & !far_only;
     const bool push = !leaf & both & (tmid < L.tmin);
     // leaf: the next segment starts where this one ended
     const bool finished = leaf & (L.ext >= L.tmin);
     const bool cont = leaf & !finished;
-    const bool pop = cont & (L.cnt > 0);
-    const bool restart = cont & (L.cnt == 0) & (L.dropped != 0);
-    const bool exhausted = cont & (L.cnt == 0) & (L.dropped == 0);
-    const uint32_t ptop = (L.top - 1u) & slot_mask;
-    const uint2 e = stk[ptop * 64];                                // harmless when not popping
-    stk[L.top * 64] = make_uint2(fr, __float_as_uint(L.ext));      // slot `top` is always free
+    const bool pop_ring = cont & (L.cnt > 0);
+    const bool pop_ovf = cont & (L.cnt == 0) & (L.novf != 0);
+    const bool exhausted = cont & (L.cnt == 0) & (L.novf == 0);
+    const bool pop = pop_ring | pop_ovf;
     const bool full = L.cnt == slot_mask;
+    const uint32_t ptop = (L.top - 1u) & slot_mask;
+    uint2 e = stk[ptop * 64];                                      // harmless when not popping
+    if (pop_ovf | (push & full)) {                                 // rare: the ring ran empty or is full
+        uint2 *ovf = overflow_column(S);
+        if (pop_ovf) {
+            L.novf--;
+            e = ovf[(size_t)L.novf * 64];
+        } else if (L.novf < S.ovf_depth) {                         // always true for a tree of the depth the stack was sized for
+            ovf[(size_t)L.novf * 64] = stk[((L.top + 1u) & slot_mask) * 64];      // the oldest entry leaves the ring
+            L.novf++;
+        }
+    }
+    stk[L.top * 64] = make_uint2(fr, __float_as_uint(L.ext));      // slot `top` is always free
     const uint32_t curr = leaf ? (pop ? e.x : 0u) : (far_only ? fr : nr);
-    const float next_ext = leaf ? (pop ? __uint_as_float(e.y) : L.root_ext) : (both ? tmid : L.ext);
+    const float next_ext = leaf ? (pop ? __uint_as_float(e.y) : L.ext) : (both ? tmid : L.ext);
     L.ent = leaf ? L.ext : L.ent;
     L.ext = next_ext;
-    // ring bookkeeping: a push onto a full ring overwrites the oldest entry (the free slot moves on)
-    L.top = push ? ((L.top + 1u) & slot_mask) : (pop ? ptop : L.top);
-    L.cnt = push ? (full ? L.cnt : L.cnt + 1u) : (pop ? L.cnt - 1u : L.cnt);
-    L.dropped = restart ? 0u : ((push & full) ? 1u : L.dropped);
+    // ring bookkeeping: a push onto a full ring takes the slot its oldest entry has just left
+    L.top = push ? ((L.top + 1u) & slot_mask) : (pop_ring ? ptop : L.top);
+    L.cnt = push ? (full ? L.cnt : L.cnt + 1u) : (pop_ring ? L.cnt - 1u : L.cnt);
     L.steps++;
     const bool done = finished | exhausted | (L.steps > FS_MAX_STEPS);
     load_node(L, S, done ? 0u : curr);

@@ -33,7 +33,7 @@ struct Builder {
     int v(double x, double y, double z) { m.vert.push_back({x, y, z}); return (int)m.vert.size() - 1; }
     int n(double x, double y, double z) {
         double l = std::sqrt(x * x + y * y + z * z);
-        if (l == 0) { x = 0; y = 1; z = 0; l = 1; }
+        if (!(l > 0) || !std::isfinite(l)) { x = 0; y = 1; z = 0; l = 1; }
         m.norm.push_back({x / l, y / l, z / l});
         return (int)m.norm.size() - 1;
     }
@@ -59,7 +59,9 @@ struct Builder {
         for (int i = 0; i <= na; i++)
             for (int j = 0; j <= nb; j++) {
                 double a = (double)i / na, b = (double)j / nb;
-                D3 p = P(a, b), pa = P(a + e, b), pb = P(a, b + e), qa = P(a - e, b), qb = P(a, b - e);
+                // differences stay inside [0, 1]: profile functions need not be defined outside
+                D3 p = P(a, b), pa = P(std::min(a + e, 1.0), b), pb = P(a, std::min(b + e, 1.0)), qa = P(std::max(a - e, 0.0), b),
+                   qb = P(a, std::max(b - e, 0.0));
                 D3 da{pa[0] - qa[0], pa[1] - qa[1], pa[2] - qa[2]}, db{pb[0] - qb[0], pb[1] - qb[1], pb[2] - qb[2]};
                 size_t k = (size_t)i * (nb + 1) + j;
                 vi[k] = v(p[0], p[1], p[2]);
