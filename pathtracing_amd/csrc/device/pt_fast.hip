@@ -377,10 +377,10 @@ struct ShadowPolicy {
             light_f(S.lightsF, k, px, py, pz, lx, ly, lz, dis, sr, sg, sb);
             const float c = lx * nrm.x + ly * nrm.y + lz * nrm.z;
             if (c > 0.0f) {
-                shadow++;
                 const float4 ng = S.triNgF[tri];
                 const bool self = (lx * ng.x + ly * ng.y + lz * ng.z) * (nrm.x * ng.x + nrm.y * ng.y + nrm.z * ng.z) < 0.0f;
                 if (!self) {
+                    shadow++;                                         // rays traced, not lights considered
                     pr = c * sr; pg = c * sg; pb = c * sb;
                     if (lane_begin(L, S, box, px, py, pz, lx, ly, lz, dis, tri)) return true;
                     dr += pr; dg += pg; db += pb;                     // ray misses the scene box: visible

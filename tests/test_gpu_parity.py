@@ -133,18 +133,25 @@ def test_fast_trace_against_brute_force(gpu_scenes, oracle_scenes, name):
     tmin = np.full(len(src), device.FLT_MAX)
     g = gpu_scenes(name).trace(src, d, tmin, mode=1)
     o = s.trace(src, d, tmin, mode=1)
+    check_fast_trace(g, o)
+
+
+def check_fast_trace(g, o):
+    """Measured on MI355X (cbox, car, atrium-20k; 20 000 rays each): no found/miss disagreement, the same
+    triangle on every ray, relative error of t 5e-5 at the 99.9th percentile (fp32 cancellation on grazing hits)."""
     both = (g["found"] == 1) & (o["found"] == 1)
-    assert (g["found"] != o["found"]).mean() < 2e-3
+    assert (g["found"] != o["found"]).mean() <= 1e-4
     same = both & (g["mesh"] == o["mesh"]) & (g["tri"] == o["tri"])
-    assert same.sum() / both.sum() > 0.995
+    assert same.sum() / both.sum() >= 0.9995
     rel = np.abs(g["t"][same] - o["t"][same]) / o["t"][same]
-    assert np.quantile(rel, 0.999) < 1e-5, rel.max()
+    assert np.median(rel) < 1e-6 and np.quantile(rel, 0.999) < 3e-4, (np.median(rel), np.quantile(rel, 0.999))
 
 
 @pytest.mark.parametrize("name,model", [("cbox", 0), ("cbox", 1), ("car", 0), ("car", 1)])
 def test_fast_gi_image_close_to_exact(gpu_scenes, host_scenes, name, model):
     """fp32 GI wavefront path vs fp64 path at equal spp and equal sample directions:
-    RMSE of the linear image below 2e-3 (measured: a few 1e-4), primary outputs identical."""
+    RMSE of the linear image below 5e-4 (measured: at most 1.4e-4), fewer than 5 in 10 000 bytes of the
+    8-bit frame differ (measured: below 1 in 10 000), primary outputs identical."""
     c = cam_of(host_scenes(name))
     sc = gpu_scenes(name)
     a = sc.render(**c, model=model, gi=True, spp=8, gi_precision=device.GI_F64_EXACT)
@@ -152,8 +159,9 @@ def test_fast_gi_image_close_to_exact(gpu_scenes, host_scenes, name, model):
     for k in ("mesh", "tri", "t", "gclr", "gnrm", "ghit"):
         assert np.array_equal(a[k], b[k])
     rmse = float(np.sqrt(np.mean((a["rgb"] - b["rgb"]) ** 2)))
-    assert rmse < 2e-3, rmse
-    assert abs(a["rgb"].mean() - b["rgb"].mean()) < 2e-4
+    assert rmse < 5e-4, rmse
+    assert abs(a["rgb"].mean() - b["rgb"].mean()) < 5e-6
+    assert (a["bgr"] != b["bgr"]).mean() < 5e-4
     assert a["stats"]["gi"] == b["stats"]["gi"]
     # bit-reproducible run to run (contribution slots, no float atomics)
     b2 = sc.render(**c, model=model, gi=True, spp=8, gi_precision=device.GI_F32_FAST)
@@ -208,10 +216,20 @@ def test_atrium_exact_and_fast(atrium_small):
         o = orc.render(**c, model=model, gi=True, spp=2, size=160, threads=16)
         assert_same_frame(g, o, f"atrium-20k model {model}")
         f = ds.render(**c, model=model, gi=True, spp=2, size=160, gi_precision=device.GI_F32_FAST)
-        rmse = float(np.sqrt(np.nanmean((f["rgb"] - g["rgb"]) ** 2)))
-        assert rmse < 3e-3, rmse
+        rmse = float(np.sqrt(np.mean((f["rgb"] - g["rgb"]) ** 2)))
+        assert rmse < 1e-3, rmse                      # measured 1.5e-5; one differing sample of the 2 moves a pixel a lot
+        assert (f["bgr"] != g["bgr"]).mean() < 1e-3
     info = ds.info()
     assert info["dev_nodes"] > 0 and info["dev_max_leaf"] <= 64
+
+
+def test_atrium_fast_trace_against_brute_force(atrium_small):
+    """Axis-aligned walls and floors sit in cells of zero thickness in the fp32 tree; rays that end on them
+    (every ray in a closed hall) must find them."""
+    hs, orc, ds = atrium_small
+    src, d = random_rays(20000, 13, orc.root_box())
+    tmin = np.full(len(src), device.FLT_MAX)
+    check_fast_trace(ds.trace(src, d, tmin, mode=1), orc.trace(src, d, tmin, mode=1))
 
 
 def test_ring_overflow_to_device_stack(atrium_small, monkeypatch):
