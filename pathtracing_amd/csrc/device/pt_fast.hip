@@ -183,10 +183,10 @@ struct ClosestPolicy {
     LaneState L;
     uint32_t r, work[2];
     __device__ __forceinline__ void census() { if (COUNT) { work[0]++; work[1] += (L.tend - L.toff) / 48u; } }
-    __device__ __forceinline__ bool turn() {
-        if (!lane_turn<false, COUNT>(L, S, stk, slot_mask, work)) return true;
-        Q.hits[r] = make_float4(L.tmin, L.hu, L.hv, __int_as_float(L.htri));
-        return false;
+    __device__ __forceinline__ bool step(bool active) {
+        const bool done = lane_turn<false, COUNT>(L, S, stk, slot_mask, work, active);
+        if (done) Q.hits[r] = make_float4(L.tmin, L.hu, L.hv, __int_as_float(L.htri));
+        return active & !done;
     }
     __device__ __forceinline__ bool start(uint32_t item) {
         r = item;
@@ -358,6 +358,7 @@ struct ShadowPolicy {
     // A turn: one unit of the running shadow ray; when it ends (or the point is new), find the
     // next light in front of the surface and begin its ray, or complete the point when there
     // is none (a light behind the surface adds 0 whatever its ray says).
+    __device__ __forceinline__ bool step(bool active) { return active ? turn() : false; }
     __device__ __forceinline__ bool turn() {
         if (!fresh) {
             if (!lane_turn<true, false>(L, S, stk, slot_mask, nullptr)) return true;
@@ -438,6 +439,7 @@ struct RawPolicy {
         miss();
         return false;
     }
+    __device__ __forceinline__ bool step(bool active) { return active ? turn() : false; }
     __device__ __forceinline__ bool turn() {
         if (!lane_turn<false, false>(L, S, stk, slot_mask, nullptr)) return true;
         if (L.htri < 0) { miss(); return false; }

@@ -44,6 +44,6 @@ __device__ __forceinline__ void persistent_loop(Policy &P, uint32_t n_items, uin
             if (!more) break;
             continue;
         }
-        if (active) active = P.turn();
+        active = P.step(active);
     }
 }

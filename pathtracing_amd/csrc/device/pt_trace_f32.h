@@ -91,8 +91,9 @@ __device__ __forceinline__ uint2 *overflow_column(const DevScene &S) {
 }
 
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2 *stk, uint32_t slot_mask, uint32_t *work) {
-    if (L.toff < L.tend) {
+__device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2 *stk, uint32_t slot_mask, uint32_t *work, bool active = true) {
+    bool done = false;
+    if (active & (L.toff < L.tend)) {
         // ---- one triangle of the current node (Moeller-Trumbore, two-sided) ----
         const float4 *tp = (const float4 *)((const char *)S.refTriF + L.toff);
         const float4 A = tp[0], B = tp[1], C = tp[2];
@@ -109,8 +110,9 @@ __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2
         // every comparison is false for a NaN, so a degenerate triangle never hits
         bool hit = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f) & (t < L.tmin) & (id != L.skip);
         L.tmin = hit ? t : L.tmin; L.hu = hit ? u : L.hu; L.hv = hit ? v : L.hv; L.htri = hit ? id : L.htri;
-        return ANY && hit;
+        if (ANY) done = hit;
     }
+    if (active & !(L.toff < L.tend) & !done) {
     // ---- one node step ----
     const bool leaf = L.nlink == 0xFFFFFFFFu;
     const uint32_t axis = L.nlink & 3u, left = L.nlink & ~15u;
@@ -154,8 +156,9 @@ __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2
     L.top = push ? ((L.top + 1u) & slot_mask) : (pop_ring ? ptop : L.top);
     L.cnt = push ? (full ? L.cnt : L.cnt + 1u) : (pop_ring ? L.cnt - 1u : L.cnt);
     L.steps++;
-    const bool done = finished | exhausted | (L.steps > FS_MAX_STEPS);
+    done = finished | exhausted | (L.steps > FS_MAX_STEPS);
     load_node(L, S, done ? 0u : curr);
     if (COUNT && !done) { work[0]++; work[1] += (L.tend - L.toff) / 48u; }
+    }
     return done;
 }
