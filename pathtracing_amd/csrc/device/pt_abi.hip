@@ -220,8 +220,9 @@ int upload(const PtSceneDesc *d, PtScene **out) {
         double o[9];
         tri9(frefs[r], o);
         rtf[3 * r] = make_float4((float)o[0], (float)o[1], (float)o[2], bits_to_float(frefs[r]));
-        rtf[3 * r + 1] = make_float4((float)o[3], (float)o[4], (float)o[5], 0.f);
-        rtf[3 * r + 2] = make_float4((float)o[6], (float)o[7], (float)o[8], 0.f);
+        // the two edges interleaved, e2 first: the pairs the packed-fp32 triangle test multiplies
+        rtf[3 * r + 1] = make_float4((float)o[6], (float)o[3], (float)o[7], (float)o[4]);
+        rtf[3 * r + 2] = make_float4((float)o[8], (float)o[5], 0.f, 0.f);
     }
     // ---- textures flattened into one byte pool ----
     std::vector<int64_t> toff(d->n_tex);

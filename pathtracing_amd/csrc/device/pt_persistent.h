@@ -40,10 +40,10 @@ __device__ __forceinline__ void persistent_loop(Policy &P, uint32_t n_items, uin
                 if (k < take) active = P.start(base + k);
             }
         }
-        if (!__any(active)) {
-            if (!more) break;
-            continue;
-        }
+        // a single back edge: when no lane is active (only while the last chunk is being handed out) the step
+        // below runs with every lane predicated off rather than being jumped over, which keeps the lane state in
+        // one set of registers around the loop
+        if (!more && !__any(active)) break;
         active = P.step(active);
     }
 }

@@ -42,7 +42,7 @@ struct DevScene {
     const int32_t *refId;      // triangle index per ref
     // ---- fp32 fast path ----
     const NodeF *nodeF;
-    const float4 *refTriF;     // 3 float4 per ref: (v0, id bits), (e1, 0), (e2, 0)
+    const float4 *refTriF;     // 3 float4 per ref: (v0, id bits), (e2.x, e1.x, e2.y, e1.y), (e2.z, e1.z, 0, 0)
     uint2 *ovf;                // traversal overflow stack: [wave][entry][lane], ovf_depth entries per lane, ovf_waves waves
     uint32_t ovf_depth, ovf_waves;
     const double *triGeo;      // 9 per triangle (by triangle index): v0, v1 - v0, v2 - v0

@@ -16,7 +16,8 @@
 //             children are adjacent, right = left + 16 bytes
 //   tri_off : byte offset of the node's first 48-byte triangle record
 //   tri_end : byte offset one past its last
-// Triangle record (48 bytes): v0.xyz, triangle index | e1.xyz, 0 | e2.xyz, 0.
+// Triangle record (48 bytes): v0.xyz, triangle index | e2.x, e1.x, e2.y, e1.y | e2.z, e1.z, 0, 0
+// (e1 = v1 - v0, e2 = v2 - v0; the edges are interleaved for the packed-fp32 test).
 //
 // The traversal is an exact nearest-hit search over the triangles of all visited
 // nodes: triangles held by interior nodes are tested on the way down, a leaf's
@@ -38,8 +39,11 @@
 
 #define FS_MAX_STEPS 200000    // hard bound on node steps per ray: every lane, so every wave, terminates
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct LaneState {
-    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
+    float ox, oy, oz, ix, iy, iz;
+    f32x2 dtx, dty, dtz;                // .x: ray direction component; .y: scratch of the triangle test (o - v0)
     float tmin, ent, ext, hu, hv;
     int htri, skip;
     uint32_t top, cnt, steps, novf;
@@ -66,7 +70,7 @@ __device__ __forceinline__ void load_node(LaneState &L, const DevScene &S, uint3
 // Start a ray; false when it misses the scene's box (nothing to traverse).
 __device__ __forceinline__ bool lane_begin(LaneState &L, const DevScene &S, const RootBox &b, float ox, float oy, float oz,
                                            float dx, float dy, float dz, float tmax, int skip) {
-    L.ox = ox; L.oy = oy; L.oz = oz; L.dx = dx; L.dy = dy; L.dz = dz;
+    L.ox = ox; L.oy = oy; L.oz = oz; L.dtx.x = dx; L.dty.x = dy; L.dtz.x = dz;
     L.ix = __builtin_amdgcn_rcpf(dx); L.iy = __builtin_amdgcn_rcpf(dy); L.iz = __builtin_amdgcn_rcpf(dz);
     float a0 = (b.lx - ox) * L.ix, a1 = (b.hx - ox) * L.ix;
     float b0 = (b.ly - oy) * L.iy, b1 = (b.hy - oy) * L.iy;
@@ -98,14 +102,16 @@ __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2
         const float4 *tp = (const float4 *)((const char *)S.refTriF + L.toff);
         const float4 A = tp[0], B = tp[1], C = tp[2];
         L.toff += 48u;
-        float px = L.dy * C.z - L.dz * C.y, py = L.dz * C.x - L.dx * C.z, pz = L.dx * C.y - L.dy * C.x;
-        float det = px * B.x + py * B.y + pz * B.z;
-        float inv = __builtin_amdgcn_rcpf(det);
-        float tx = L.ox - A.x, ty = L.oy - A.y, tz = L.oz - A.z;
-        float u = (px * tx + py * ty + pz * tz) * inv;
-        float qx = ty * B.z - tz * B.y, qy = tz * B.x - tx * B.z, qz = tx * B.y - ty * B.x;
-        float v = (qx * L.dx + qy * L.dy + qz * L.dz) * inv;
-        float t = (qx * C.x + qy * C.y + qz * C.z) * inv;
+        // Both cross products and all four dot products of the test run as packed fp32 pairs
+        // (v_pk_mul_f32 / v_pk_fma_f32): lane .x of a pair works on P = d x e2, lane .y on Q = T x e1.
+        const f32x2 ex = {B.x, B.y}, ey = {B.z, B.w}, ez = {C.x, C.y};                 // (e2, e1) per axis
+        L.dtx.y = L.ox - A.x; L.dty.y = L.oy - A.y; L.dtz.y = L.oz - A.z;              // (d, T = o - v0)
+        const f32x2 dtx = L.dtx, dty = L.dty, dtz = L.dtz;
+        const f32x2 pqx = dty * ez - dtz * ey, pqy = dtz * ex - dtx * ez, pqz = dtx * ey - dty * ex;   // (P, Q)
+        const f32x2 dn = pqx * ex.yx + pqy * ey.yx + pqz * ez.yx;                      // (det = P . e1, Q . e2)
+        const f32x2 uvn = pqx * dtx.yx + pqy * dty.yx + pqz * dtz.yx;                  // (P . T, Q . d)
+        const float inv = __builtin_amdgcn_rcpf(dn.x);
+        const float u = uvn.x * inv, v = uvn.y * inv, t = dn.y * inv;
         int id = __float_as_int(A.w);
         // every comparison is false for a NaN, so a degenerate triangle never hits
         bool hit = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f) & (t < L.tmin) & (id != L.skip);
