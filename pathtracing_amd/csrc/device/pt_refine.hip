@@ -138,6 +138,31 @@ struct Builder {
     }
 };
 
+// Re-number the nodes so that every pair of children starts at an even index (32-byte aligned in
+// the encoded array): the traversal then gets the far child as near ^ 16.  Depth-first, a pair
+// placed when its parent is reached.
+void align_pairs(std::vector<NodeF> &nodes) {
+    std::vector<NodeF> out;
+    out.reserve(nodes.size() + 2);
+    out.push_back(nodes[0]);
+    out.push_back(NodeF{0.f, 0xFFFFFFFFu, 0u, 0u});            // never referenced
+    std::vector<std::pair<uint32_t, uint32_t>> todo;          // (old index, new index)
+    todo.push_back({0u, 0u});
+    while (!todo.empty()) {
+        auto [o, n] = todo.back();
+        todo.pop_back();
+        const NodeF src = nodes[o];
+        if (src.link == 0xFFFFFFFFu) continue;
+        const uint32_t old_left = src.link & 0x3FFFFFFFu, axis = src.link >> 30, new_left = (uint32_t)out.size();
+        out.push_back(nodes[old_left]);
+        out.push_back(nodes[old_left + 1]);
+        out[n].link = new_left | (axis << 30);
+        todo.push_back({old_left + 1, new_left + 1});
+        todo.push_back({old_left, new_left});
+    }
+    nodes.swap(out);
+}
+
 }  // namespace
 
 RefineStats refine_tree(const PtSceneDesc *d, const RefineParams &prm, std::vector<NodeF> &nodes, std::vector<int32_t> &refs) {
@@ -165,6 +190,7 @@ RefineStats refine_tree(const PtSceneDesc *d, const RefineParams &prm, std::vect
         Box3 box;
         for (int c = 0; c < 3; c++) { box.lo[c] = (float)d->nodes[0].lo[c]; box.hi[c] = (float)d->nodes[0].hi[c]; }
         b.build(0, box, all, 0);
+        align_pairs(nodes);
         b.st.nodes = nodes.size();
         b.st.refs = refs.size();
         return b.st;
@@ -194,6 +220,7 @@ RefineStats refine_tree(const PtSceneDesc *d, const RefineParams &prm, std::vect
         }
         b.build(k, box, ids, depth[k]);
     }
+    align_pairs(nodes);
     b.st.nodes = nodes.size();
     b.st.refs = refs.size();
     return b.st;

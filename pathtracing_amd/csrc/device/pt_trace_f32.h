@@ -13,7 +13,7 @@
 // Node record (16 bytes, four to a 64-byte line):
 //   split | link | tri_off | tri_end
 //   link    : 0xFFFFFFFF for a leaf, else (byte offset of the left child) | axis;
-//             children are adjacent, right = left + 16 bytes
+//             children are adjacent and the pair is 32-byte aligned: right = left + 16 = left ^ 16
 //   tri_off : byte offset of the node's first 48-byte triangle record
 //   tri_end : byte offset one past its last
 // Triangle record (48 bytes): v0.xyz, triangle index | e2.x, e1.x, e2.y, e1.y | e2.z, e1.z, 0, 0
@@ -46,7 +46,7 @@ struct LaneState {
     f32x2 dtx, dty, dtz;                // .x: ray direction component; .y: scratch of the triangle test (o - v0)
     float tmin, ent, ext, hu, hv;
     int htri, skip;
-    uint32_t top, cnt, steps, novf;
+    uint32_t top, cs, novf;             // ring: free slot, (node steps << 8 | entries in the ring), entries in the overflow stack
     float nsplit;                       // current node
     uint32_t nlink, toff, tend;
 };
@@ -78,7 +78,7 @@ __device__ __forceinline__ bool lane_begin(LaneState &L, const DevScene &S, cons
     L.ent = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
     L.ext = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tmax));
     L.tmin = tmax; L.htri = -1; L.hu = 0; L.hv = 0; L.skip = skip;
-    L.top = 0; L.cnt = 0; L.steps = 0; L.novf = 0;
+    L.top = 0; L.cs = 0; L.novf = 0;
     if (!(L.ent <= L.ext)) return false;
     load_node(L, S, 0);
     return true;
@@ -124,8 +124,7 @@ __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2
     const uint32_t axis = L.nlink & 3u, left = L.nlink & ~15u;
     const float oa = sel3(axis, L.ox, L.oy, L.oz), ia = sel3(axis, L.ix, L.iy, L.iz);
     const float tmid = (L.nsplit - oa) * ia;
-    const uint32_t side = oa > L.nsplit ? 16u : 0u;
-    const uint32_t nr = left + side, fr = left + 16u - side;
+    const uint32_t nr = left + (oa > L.nsplit ? 16u : 0u), fr = nr ^ 16u;
     // A plane met exactly at the segment's start or end sends the ray into BOTH children: a cell of
     // zero length along the ray may be the thin cell that holds an axis-aligned wall or floor
     // (the tree builder isolates those), and its triangles have to be tested.
@@ -134,13 +133,14 @@ __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2
     const bool both = !near_only & !far_only;
     const bool push = !leaf & both & (tmid < L.tmin);
     // leaf: the next segment starts where this one ended
+    const uint32_t cnt = L.cs & 0xFFu;
     const bool finished = leaf & (L.ext >= L.tmin);
     const bool cont = leaf & !finished;
-    const bool pop_ring = cont & (L.cnt > 0);
-    const bool pop_ovf = cont & (L.cnt == 0) & (L.novf != 0);
-    const bool exhausted = cont & (L.cnt == 0) & (L.novf == 0);
+    const bool pop_ring = cont & (cnt != 0);
+    const bool pop_ovf = cont & (cnt == 0) & (L.novf != 0);
+    const bool exhausted = cont & (cnt == 0) & (L.novf == 0);
     const bool pop = pop_ring | pop_ovf;
-    const bool full = L.cnt == slot_mask;
+    const bool full = cnt == slot_mask;
     const uint32_t ptop = (L.top - 1u) & slot_mask;
     uint2 e = stk[ptop * 64];                                      // harmless when not popping
     if (pop_ovf | (push & full)) {                                 // rare: the ring ran empty or is full
@@ -154,16 +154,16 @@ __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2
         }
     }
     stk[L.top * 64] = make_uint2(fr, __float_as_uint(L.ext));      // slot `top` is always free
+    // next node: a leaf that neither pops nor restarts loads the root again, harmlessly (the ray is done)
     const uint32_t curr = leaf ? (pop ? e.x : 0u) : (far_only ? fr : nr);
     const float next_ext = leaf ? (pop ? __uint_as_float(e.y) : L.ext) : (both ? tmid : L.ext);
     L.ent = leaf ? L.ext : L.ent;
     L.ext = next_ext;
     // ring bookkeeping: a push onto a full ring takes the slot its oldest entry has just left
     L.top = push ? ((L.top + 1u) & slot_mask) : (pop_ring ? ptop : L.top);
-    L.cnt = push ? (full ? L.cnt : L.cnt + 1u) : (pop_ring ? L.cnt - 1u : L.cnt);
-    L.steps++;
-    done = finished | exhausted | (L.steps > FS_MAX_STEPS);
-    load_node(L, S, done ? 0u : curr);
+    L.cs += 256u + (uint32_t)(push & !full) - (uint32_t)pop_ring;
+    done = finished | exhausted | (L.cs > ((uint32_t)FS_MAX_STEPS << 8));
+    load_node(L, S, curr);
     if (COUNT && !done) { work[0]++; work[1] += (L.tend - L.toff) / 48u; }
     }
     return done;
