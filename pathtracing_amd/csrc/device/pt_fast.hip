@@ -96,25 +96,27 @@ __device__ __forceinline__ bool origin_triangle_hit(const double *T9, D3 o, D3 w
 // direction bin (counting sort in LDS), so that the 64 rays a wave of the closest-hit kernel
 // draws together start close to each other and point the same way.  Queue order is free: the
 // contribution slot travels with the ray.
-#define PT_GEN_BINS 64
+#define PT_GEN_AXIS_BITS 3                          // direction cells per axis = 1 << bits
+#define PT_GEN_BINS (1 << (3 * PT_GEN_AXIS_BITS))
 __device__ __forceinline__ uint32_t dir_bin(float x, float y, float z) {
-    // 4 x 4 x 4 cells of the cube [-1, 1]^3 that contains the unit sphere
-    uint32_t qx = (uint32_t)fminf(fmaxf((x * 0.5f + 0.5f) * 4.0f, 0.0f), 3.0f);
-    uint32_t qy = (uint32_t)fminf(fmaxf((y * 0.5f + 0.5f) * 4.0f, 0.0f), 3.0f);
-    uint32_t qz = (uint32_t)fminf(fmaxf((z * 0.5f + 0.5f) * 4.0f, 0.0f), 3.0f);
-    return (qx << 4) | (qy << 2) | qz;
+    // cells of the cube [-1, 1]^3 that contains the unit sphere; about a sixth of them meet a hemisphere
+    const float n = (float)(1 << PT_GEN_AXIS_BITS), hi = n - 1.0f;
+    uint32_t qx = (uint32_t)fminf(fmaxf((x * 0.5f + 0.5f) * n, 0.0f), hi);
+    uint32_t qy = (uint32_t)fminf(fmaxf((y * 0.5f + 0.5f) * n, 0.0f), hi);
+    uint32_t qz = (uint32_t)fminf(fmaxf((z * 0.5f + 0.5f) * n, 0.0f), hi);
+    return (qx << (2 * PT_GEN_AXIS_BITS)) | (qy << PT_GEN_AXIS_BITS) | qz;
 }
 
 __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, FrameBuffers F, FastBuffers Q, int s0, int nb, int groups) {
     __shared__ uint32_t hist[PT_GEN_BINS];
     __shared__ uint32_t bin_base[PT_GEN_BINS];
-    __shared__ uint32_t block_base;
+    __shared__ uint32_t block_base, wave_sum[16];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x / groups, group = blockIdx.x - tile * groups;
     int i, j;
     const bool live = tile_pixel_f(tile * 64 + (tid & 63), V.size, i, j);
     const size_t P = (size_t)V.size * V.size, p = live ? (size_t)i * V.size + j : 0;
-    if (tid < PT_GEN_BINS) hist[tid] = 0;
+    for (int k = tid; k < PT_GEN_BINS; k += 1024) hist[k] = 0;
     __syncthreads();
     bool pix_valid = false;
     float4 ro = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -153,10 +155,25 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t tot = 0;
-        for (int k = 0; k < PT_GEN_BINS; k++) { bin_base[k] = tot; tot += hist[k]; }
-        block_base = tot ? atomicAdd(&Q.counts[0], tot) : 0u;
+    {
+        // exclusive prefix sum of the histogram: a run of bins per thread, a scan per wave, a scan over the 16 waves
+        constexpr int RUN = (PT_GEN_BINS + 1023) / 1024;
+        const int lane = tid & 63, wave = tid >> 6, first = tid * RUN;
+        uint32_t local = 0;
+        for (int k = 0; k < RUN; k++) local += first + k < PT_GEN_BINS ? hist[first + k] : 0u;
+        uint32_t incl = local;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t nbr = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += nbr;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int w = 0; w < 16; w++) { before += w < wave ? wave_sum[w] : 0u; total += wave_sum[w]; }
+        uint32_t run = before + incl - local;
+        for (int k = 0; k < RUN; k++)
+            if (first + k < PT_GEN_BINS) { bin_base[first + k] = run; run += hist[first + k]; }
+        if (tid == 0) block_base = total ? atomicAdd(&Q.counts[0], total) : 0u;
     }
     __syncthreads();
 #pragma unroll
