@@ -182,11 +182,15 @@ def main():
 
     if rank == 0:
         # ---- algorithmic bytes per ray of the dominant kernel: a counting run (untimed) ----
-        cst = device.PtStats()
-        ds.render_to_device(views[a.warmup % nviews], frame.data_ptr(), stats=cst, view=a.warmup % nviews,
-                            flags=device.FLAG_COUNT_WORK, **opt)
-        n_node = cst.gi_nodes_visited / max(cst.gi, 1)
-        n_tri = cst.gi_tris_tested / max(cst.gi, 1)
+        # over exactly the views the timed steps of this rank rendered
+        c_gi = c_node = c_tri = 0
+        for i in range(a.steps):
+            v = ((a.warmup + i) * world + rank) % nviews
+            cst = device.PtStats()
+            ds.render_to_device(views[v], frame.data_ptr(), stats=cst, view=v, flags=device.FLAG_COUNT_WORK, **opt)
+            c_gi += cst.gi; c_node += cst.gi_nodes_visited; c_tri += cst.gi_tris_tested
+        n_node = c_node / max(c_gi, 1)
+        n_tri = c_tri / max(c_gi, 1)
         # per closest-hit ray: 32 B ray in + 16 B hit out + 16 B per node visited + (4 + 36) B per triangle tested
         bytes_per_ray = 32 + 16 + 16 * n_node + 40 * n_tri
         launches = max(stats.gi_trace_launches, 1)

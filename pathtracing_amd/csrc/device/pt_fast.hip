@@ -23,8 +23,8 @@
 #pragma clang fp contract(fast)
 
 #define FS_SLOTS 8                  // ring entries per lane in LDS (one of them is kept free)
-#define PT_REFILL_MIN 8             // idle lanes that trigger a refill
-#define PT_QUEUE_CHUNK 128          // work items a wave takes from the queue head per atomicAdd (upper bound)
+#define PT_REFILL_MIN 16             // idle lanes that trigger a refill
+#define PT_QUEUE_CHUNK 64          // work items a wave takes from a queue head per atomicAdd
 
 // Queue append for a whole workgroup: ballot + prefix popcount inside each wave, a
 // scan over the block's waves in LDS, ONE atomicAdd per block.  (One atomicAdd per
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q,
     extern __shared__ uint2 stack[];            // (slot_mask + 1) * 64 entries
     ClosestPolicy<COUNT> P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
     P.work[0] = P.work[1] = 0;
-    persistent_loop(P, Q.counts[0], &Q.counts[3], chunk, refill_min);
+    persistent_loop(P, Q.counts[0], Q.heads, chunk, refill_min);
     if (COUNT) {
         for (int k = 0; k < 2; k++) {
             uint32_t v = P.work[k];
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(64) k_shadow_gi(DevScene S, FastBuffers Q, uin
     extern __shared__ uint2 stack[];
     ShadowPolicy P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
     P.shadow = 0; P.fresh = false;
-    persistent_loop(P, Q.counts[1], &Q.counts[4], chunk, refill_min);
+    persistent_loop(P, Q.counts[1], Q.heads + PT_HEAD_WORDS, chunk, refill_min);
     uint32_t n = P.shadow;
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(&Q.counts[2], n);
@@ -486,6 +486,7 @@ int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *
     FA(sp_pos, float4); FA(sp_nrm, float4); FA(sp_base, float4); FA(contrib, float4);
 #undef FA
     if ((rc = alloc(ctx, 8 * sizeof(uint32_t), (void **)&Q.counts))) return rc;
+    if ((rc = alloc(ctx, 2 * PT_HEAD_WORDS * sizeof(uint32_t), (void **)&Q.heads))) return rc;
     if ((rc = alloc(ctx, 2 * sizeof(unsigned long long), (void **)&Q.work))) return rc;
     return PT_OK;
 }
@@ -499,7 +500,7 @@ static TraceTune trace_tune() {
         TraceTune v{FS_SLOTS, PT_REFILL_MIN, PT_TRACE_WAVES, PT_QUEUE_CHUNK};
         if (const char *e = getenv("PT_TUNE_SLOTS")) { int k = atoi(e); if (k == 2 || k == 4 || k == 8 || k == 16 || k == 32) v.slots = k; }
         if (const char *e = getenv("PT_TUNE_REFILL")) { int k = atoi(e); if (k >= 1 && k <= 64) v.refill = k; }
-        if (const char *e = getenv("PT_TUNE_CHUNK")) { int k = atoi(e); if (k >= 64 && k <= 65536) v.chunk = k; }
+        if (const char *e = getenv("PT_TUNE_CHUNK")) { int k = atoi(e); if (k >= 16 && k <= 65536) v.chunk = k; }
         if (const char *e = getenv("PT_TUNE_WAVES")) { int k = atoi(e); if (k >= 64 && k <= PT_TRACE_WAVES) v.waves = k; }
         return v;
     }();
@@ -520,6 +521,7 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         unsigned sblocks = (unsigned)((P * nb + PT_APPEND_BLOCK - 1) / PT_APPEND_BLOCK);
         unsigned qblocks = (unsigned)((P * nb + 63) / 64);
         FQ(hipMemsetAsync(Q.counts, 0, 8 * sizeof(uint32_t), s));
+        FQ(hipMemsetAsync(Q.heads, 0, 2 * PT_HEAD_WORDS * sizeof(uint32_t), s));
         {
             const int groups = (nb + 63) / 64;
             hipLaunchKernelGGL(k_gi_gen, dim3((unsigned)((tthreads / 64) * groups)), dim3(1024), 0, s, S, V, F, Q, s0, nb, groups);
@@ -527,10 +529,7 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         FQ(hipEventRecord(e0, s));
         unsigned tblocks = qblocks < (unsigned)tune.waves ? qblocks : (unsigned)tune.waves;
         size_t lds = (size_t)tune.slots * 64 * sizeof(uint2);
-        // queue chunk per atomicAdd: large enough to keep the queue head cold, small enough
-        // that every resident wave gets several chunks
-        uint32_t chunk = (uint32_t)((P * nb) / ((size_t)tune.waves * 4));
-        chunk = chunk < 64 ? 64 : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
+        const uint32_t chunk = (uint32_t)tune.chunk;      // smallest queue chunk (pt_persistent.h)
         if (work)
             hipLaunchKernelGGL(k_trace_closest<true>, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
         else
@@ -563,8 +562,9 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
 int fast_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
                int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s) {
     uint32_t *head = nullptr;
-    if (hipMalloc((void **)&head, sizeof(uint32_t)) != hipSuccess) return PT_ERR_HIP;
-    hipError_t e = hipMemsetAsync(head, 0, sizeof(uint32_t), s);
+    if (n >= (1ull << 31)) return PT_ERR_LIMIT;
+    if (hipMalloc((void **)&head, PT_HEAD_WORDS * sizeof(uint32_t)) != hipSuccess) return PT_ERR_HIP;
+    hipError_t e = hipMemsetAsync(head, 0, PT_HEAD_WORDS * sizeof(uint32_t), s);
     const TraceTune tune = trace_tune();
     unsigned blocks = (unsigned)((n + 63) / 64);
     if (blocks > (unsigned)tune.waves) blocks = (unsigned)tune.waves;

@@ -49,7 +49,8 @@ struct FastBuffers {
     float4 *sp_nrm;           // normal xyz, slot bits
     float4 *sp_base;          // r1 * 0.6 * txt * albedo / pi, unused
     float4 *contrib;          // per slot: r1 * radiance of the sample ray
-    uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2] shadow rays traced, [3] / [4] queue heads of the closest-hit / shadow kernels
+    uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2] shadow rays traced
+    uint32_t *heads;          // queue heads of the closest-hit kernel, then of the shadow kernel (pt_persistent.h)
     unsigned long long *work; // [0] nodes visited, [1] triangles tested (counting build of the closest-hit kernel)
     size_t max_rays;
 };

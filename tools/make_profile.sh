@@ -7,12 +7,12 @@ TAG=${2:-$W}
 OUT=gpurun_out/profile_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline"
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k -- python3 $ARGS > "$OUT/trace.log" 2>&1 || { echo "kernel trace failed"; exit 1; }
+ARGS="bench.py --workload $W --no-cpu-baseline"      # the default run of bench.py minus the CPU leg
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k -- python3 $ARGS > "$OUT/trace.log" 2>&1 || { echo "kernel trace failed"; exit 1; }
 grep "^{" "$OUT/trace.log" > "$OUT/bench_under_trace.json"
 run() {
   name=$1; shift
-  timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- python3 $ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; return 1; }
+  timeout -s KILL 400 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- python3 $ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; return 1; }
   echo "pass $name ok"
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE && \
