@@ -91,6 +91,56 @@ __device__ __forceinline__ bool origin_triangle_hit(const double *T9, D3 o, D3 w
     return uu >= 0.0 && vv >= 0.0 && uu + vv <= 1.0 && tt > 0.0;
 }
 
+// Queue order of the 8x8 pixel tiles: along a Z curve when the image is a power of two of tiles wide, so that a
+// run of consecutive tiles -- what the waves of an XCD work on at the same time -- is a compact patch of the image.
+__device__ __forceinline__ uint32_t compact_bits(uint32_t v) {
+    v &= 0x55555555u;
+    v = (v | (v >> 1)) & 0x33333333u;
+    v = (v | (v >> 2)) & 0x0F0F0F0Fu;
+    v = (v | (v >> 4)) & 0x00FF00FFu;
+    v = (v | (v >> 8)) & 0x0000FFFFu;
+    return v;
+}
+__device__ __forceinline__ int ordered_tile(int q, int size) {
+    const int tiles_x = (size + 7) >> 3;
+    if (tiles_x & (tiles_x - 1)) return q;
+    return (int)(compact_bits((uint32_t)q >> 1) * (uint32_t)tiles_x + compact_bits((uint32_t)q));
+}
+
+// Pixels with a primary hit per tile, in queue order (once per view) ...
+__global__ void k_tile_valid(FrameBuffers F, FastBuffers Q, int size, int tiles) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= tiles) return;
+    const int tile = ordered_tile(q, size);
+    uint32_t n = 0;
+    for (int l = 0; l < 64; l++) {
+        int i, j;
+        if (tile_pixel_f(tile * 64 + l, size, i, j)) n += !(F.ghit[3 * ((size_t)i * size + j)] == -99999);
+    }
+    Q.tile_base[q] = n;
+}
+// ... and their exclusive prefix sum in place, total in tile_base[tiles]: where each tile's rays start in the queue.
+__global__ void __launch_bounds__(1024) k_tile_scan(FastBuffers Q, int tiles) {
+    __shared__ uint32_t wave_sum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int run = (tiles + 1023) / 1024, first = tid * run;
+    uint32_t local = 0;
+    for (int k = 0; k < run; k++) local += first + k < tiles ? Q.tile_base[first + k] : 0u;
+    uint32_t incl = local;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t nbr = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += nbr;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < 16; w++) { before += w < wave ? wave_sum[w] : 0u; total += wave_sum[w]; }
+    uint32_t acc = before + incl - local;
+    for (int k = 0; k < run; k++)
+        if (first + k < tiles) { const uint32_t n = Q.tile_base[first + k]; Q.tile_base[first + k] = acc; acc += n; }
+    if (tid == 0) Q.tile_base[tiles] = total;
+}
+
 // One block = one 8x8 pixel tile x up to 64 samples of the pass (thread = pixel x sample lane,
 // four samples each): 4096 rays with nearby origins.  They are written to the queue sorted by
 // direction bin (counting sort in LDS), so that the 64 rays a wave of the closest-hit kernel
@@ -112,7 +162,8 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
     __shared__ uint32_t bin_base[PT_GEN_BINS];
     __shared__ uint32_t block_base, wave_sum[16];
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x / groups, group = blockIdx.x - tile * groups;
+    const int qtile = blockIdx.x / groups, group = blockIdx.x - qtile * groups;
+    const int tile = ordered_tile(qtile, V.size);
     int i, j;
     const bool live = tile_pixel_f(tile * 64 + (tid & 63), V.size, i, j);
     const size_t P = (size_t)V.size * V.size, p = live ? (size_t)i * V.size + j : 0;
@@ -173,7 +224,14 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
         uint32_t run = before + incl - local;
         for (int k = 0; k < RUN; k++)
             if (first + k < PT_GEN_BINS) { bin_base[first + k] = run; run += hist[first + k]; }
-        if (tid == 0) block_base = total ? atomicAdd(&Q.counts[0], total) : 0u;
+        // the block's place in the queue is fixed: tiles in queue order, the sample groups of a tile one after another
+        if (tid == 0) {
+            const uint32_t t0 = Q.tile_base[qtile], valid = Q.tile_base[qtile + 1] - t0;
+            const uint32_t done_samples = (uint32_t)(group * 64 < nb ? group * 64 : nb);
+            block_base = t0 * (uint32_t)nb + valid * done_samples;
+            if (blockIdx.x == 0) Q.counts[0] = Q.tile_base[gridDim.x / groups] * (uint32_t)nb;
+        }
+        (void)total;
     }
     __syncthreads();
 #pragma unroll
@@ -487,6 +545,7 @@ int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *
 #undef FA
     if ((rc = alloc(ctx, 8 * sizeof(uint32_t), (void **)&Q.counts))) return rc;
     if ((rc = alloc(ctx, 2 * PT_HEAD_WORDS * sizeof(uint32_t), (void **)&Q.heads))) return rc;
+    if ((rc = alloc(ctx, ((pixels + 63) / 64 * 4 + 2) * sizeof(uint32_t), (void **)&Q.tile_base))) return rc;
     if ((rc = alloc(ctx, 2 * sizeof(unsigned long long), (void **)&Q.work))) return rc;
     return PT_OK;
 }
@@ -515,6 +574,11 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
     const TraceTune tune = trace_tune();
     *trace_ms = 0; *launches = 0; *rays = 0; *shadow = 0;
     if (work) FQ(hipMemsetAsync(Q.work, 0, 2 * sizeof(unsigned long long), s));
+    {
+        const int tiles = tthreads / 64;
+        hipLaunchKernelGGL(k_tile_valid, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, s, F, Q, V.size, tiles);
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, Q, tiles);
+    }
     for (int s0 = 0; s0 < nsamples; s0 += batch) {
         int nb = nsamples - s0 < batch ? nsamples - s0 : batch;
         if ((size_t)nb * P > Q.max_rays) return PT_ERR_LIMIT;

@@ -50,6 +50,7 @@ struct FastBuffers {
     float4 *sp_base;          // r1 * 0.6 * txt * albedo / pi, unused
     float4 *contrib;          // per slot: r1 * radiance of the sample ray
     uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2] shadow rays traced
+    uint32_t *tile_base;      // per 8x8 tile in queue order: pixels with a primary hit before it (exclusive prefix sum; total at the end)
     uint32_t *heads;          // queue heads of the closest-hit kernel, then of the shadow kernel (pt_persistent.h)
     unsigned long long *work; // [0] nodes visited, [1] triangles tested (counting build of the closest-hit kernel)
     size_t max_rays;
