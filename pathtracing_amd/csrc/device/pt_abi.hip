@@ -263,11 +263,25 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     UP(dev_copy(sc, d->tri_local, (size_t)d->n_tri, &S.tri_local));
     UP(dev_copy(sc, d->norm, (size_t)d->n_norm * 3, &S.norm));
     {
-        std::vector<float> nf32((size_t)d->n_norm * 3), uf32((size_t)d->n_uv * 2);
-        for (size_t k = 0; k < nf32.size(); k++) nf32[k] = (float)d->norm[k];
-        for (size_t k = 0; k < uf32.size(); k++) uf32[k] = (float)d->uv[k];
-        UP(dev_copy(sc, nf32.data(), nf32.size(), &S.normF));
-        UP(dev_copy(sc, uf32.data(), uf32.size(), &S.uvF));
+        std::vector<float4> sh((size_t)d->n_tri * 5);
+        for (uint32_t t = 0; t < d->n_tri; t++) {
+            float n[9], uv[6];
+            for (int c = 0; c < 3; c++) {
+                const double *nn = d->norm + 3 * (size_t)d->tri_ni[3 * (size_t)t + c];
+                for (int k = 0; k < 3; k++) n[3 * c + k] = (float)nn[k];
+                const int32_t ui = d->tri_ti[3 * (size_t)t + c];
+                uv[2 * c] = ui >= 0 ? (float)d->uv[2 * (size_t)ui] : 0.f;
+                uv[2 * c + 1] = ui >= 0 ? (float)d->uv[2 * (size_t)ui + 1] : 0.f;
+            }
+            const double *al = d->mesh_albedo + 3 * (size_t)d->tri_mesh[t];
+            float4 *o = &sh[(size_t)t * 5];
+            o[0] = make_float4(n[0], n[1], n[2], n[3]);
+            o[1] = make_float4(n[4], n[5], n[6], n[7]);
+            o[2] = make_float4(n[8], uv[0], uv[1], uv[2]);
+            o[3] = make_float4(uv[3], uv[4], uv[5], bits_to_float(d->tri_tm[t]));
+            o[4] = make_float4((float)al[0], (float)al[1], (float)al[2], 0.f);
+        }
+        UP(dev_copy(sc, sh.data(), sh.size(), &S.triShadeF));
     }
     UP(dev_copy(sc, d->uv, (size_t)d->n_uv * 2, &S.uv));
     UP(dev_copy(sc, d->mesh_albedo, (size_t)d->n_mesh * 3, &S.albedo));

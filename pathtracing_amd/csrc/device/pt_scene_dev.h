@@ -50,7 +50,10 @@ struct DevScene {
     // ---- shading data ----
     const int32_t *tri_ni, *tri_ti, *tri_tm, *tri_reft, *tri_mesh, *tri_local;
     const double *norm, *uv, *albedo;
-    const float *normF, *uvF;  // fp32 copies of the normal and uv pools (GI fast path)
+    // GI fast path: everything surfaceProperties needs of a triangle in one 80-byte record (5 float4):
+    // n0.xyz n1.x | n1.yz n2.xy | n2.z uv0.xy uv1.x | uv1.y uv2.xy tm(int bits) | albedo.rgb of its mesh, 0
+    // (a missing uv index is stored as (0, 0), which is what the reference uses for it)
+    const float4 *triShadeF;
     const uint8_t *texels;
     const int64_t *tex_off;
     const int32_t *tex_rows, *tex_cols;
