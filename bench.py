@@ -202,7 +202,10 @@ def main():
                     "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(n_node, 2),
                     "tris_per_ray": round(n_tri, 2), "rays_per_launch": int(rays_launch),
                     "ms_per_launch": round(ms_launch, 4),
-                    "kernel_mrays_per_s": round(rays_launch / (ms_launch * 1e-3) / 1e6, 1) if ms_launch > 0 else 0.0}
+                    "kernel_mrays_per_s": round(rays_launch / (ms_launch * 1e-3) / 1e6, 1) if ms_launch > 0 else 0.0,
+                    # warm-up launches included: the figure a kernel trace of this command averages over
+                    "ms_per_launch_incl_warmup": round((stats.ms_gi_trace + warm.ms_gi_trace) /
+                                                       max(stats.gi_trace_launches + warm.gi_trace_launches, 1), 4)}
 
         tr = pmc_traffic(a.workload, rays_launch)
         if tr:
