@@ -20,8 +20,10 @@
 // Measured on MI355X, closest-hit kernel, 64 spp: atrium-262k 0.91 / 1.69 / 2.6
 // Grays/s, car 2.9 / 4.8 / 7.2 Grays/s.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 #include "pt_refine.h"
 
@@ -34,16 +36,27 @@ inline float area(const Box3 &b) {
     return 2.0f * (x * y + y * z + z * x);
 }
 
+// A subtree put aside by the top of the build, to be built by a worker thread.
+struct Job { uint32_t slot; Box3 box; std::vector<int32_t> ids; int depth; };
+
 struct Builder {
     const PtSceneDesc *d;
     RefineParams prm;
-    std::vector<Box3> tbox;               // per triangle: bounds of its fp32 vertices, slightly widened
+    std::vector<Box3> own_tbox;
+    const std::vector<Box3> &tbox;        // per triangle: bounds of its fp32 vertices, slightly widened
     std::vector<NodeF> &nodes;
     std::vector<int32_t> &refs;
     RefineStats st{};
+    std::vector<Job> *jobs = nullptr;     // when set: subtrees at `job_depth` with enough triangles are deferred
+    int job_depth = 0;
+
+    // worker: shares the triangle bounds of `top`
+    Builder(const Builder &top, std::vector<NodeF> &n, std::vector<int32_t> &r)
+        : d(top.d), prm(top.prm), tbox(top.tbox), nodes(n), refs(r) {}
 
     Builder(const PtSceneDesc *desc, const RefineParams &p, std::vector<NodeF> &n, std::vector<int32_t> &r)
-        : d(desc), prm(p), nodes(n), refs(r) {
+        : d(desc), prm(p), tbox(own_tbox), nodes(n), refs(r) {
+        std::vector<Box3> &tbox = own_tbox;
         tbox.resize(d->n_tri);
         for (uint32_t t = 0; t < d->n_tri; t++) {
             Box3 b;
@@ -68,6 +81,10 @@ struct Builder {
     // Emit node `slot` for the triangles `ids` inside `box`; children go to fresh adjacent slots.
     void build(uint32_t slot, const Box3 &box, std::vector<int32_t> &ids, int depth) {
         const size_t n = ids.size();
+        if (jobs && depth == job_depth && n > 4096) {
+            jobs->push_back(Job{slot, box, std::move(ids), depth});
+            return;
+        }
         int best_axis = -1;
         float best_plane = 0, best_cost = prm.ci * (float)n;
         if (n > (size_t)prm.leaf_keep && depth < prm.max_depth) {
@@ -138,6 +155,41 @@ struct Builder {
     }
 };
 
+// Build the subtrees the top of the build put aside, on up to 16 threads, and splice them in in job order
+// (the result does not depend on the number of threads).
+void run_jobs(Builder &top, std::vector<Job> &jobs) {
+    struct Out { std::vector<NodeF> nodes; std::vector<int32_t> refs; RefineStats st{}; };
+    std::vector<Out> outs(jobs.size());
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t j = next++; j < jobs.size(); j = next++) {
+            outs[j].nodes.assign(1, NodeF{});
+            Builder b(top, outs[j].nodes, outs[j].refs);
+            b.build(0, jobs[j].box, jobs[j].ids, jobs[j].depth);
+            outs[j].st = b.st;
+        }
+    };
+    unsigned nt = std::min<unsigned>({16u, std::max(1u, std::thread::hardware_concurrency()), (unsigned)jobs.size()});
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    for (size_t j = 0; j < jobs.size(); j++) {
+        Out &o = outs[j];
+        const uint32_t node_off = (uint32_t)top.nodes.size() - 1u, ref_off = (uint32_t)top.refs.size();
+        for (size_t k = 0; k < o.nodes.size(); k++) {
+            NodeF n = o.nodes[k];
+            if (n.link != 0xFFFFFFFFu) n.link = ((n.link & 0x3FFFFFFFu) + node_off) | (n.link & 0xC0000000u);
+            n.first += ref_off;
+            if (k == 0) top.nodes[jobs[j].slot] = n; else top.nodes.push_back(n);
+        }
+        top.refs.insert(top.refs.end(), o.refs.begin(), o.refs.end());
+        top.st.leaves += o.st.leaves; top.st.leaf_refs += o.st.leaf_refs; top.st.new_nodes += o.st.new_nodes;
+        top.st.max_leaf = std::max(top.st.max_leaf, o.st.max_leaf);
+        top.st.max_depth = std::max(top.st.max_depth, o.st.max_depth);
+    }
+}
+
 // Re-number the nodes so that every pair of children starts at an even index (32-byte aligned in
 // the encoded array): the traversal then gets the far child as near ^ 16.  Depth-first, a pair
 // placed when its parent is reached.
@@ -189,7 +241,11 @@ RefineStats refine_tree(const PtSceneDesc *d, const RefineParams &prm, std::vect
         for (uint32_t t = 0; t < d->n_tri; t++) all[t] = (int32_t)t;
         Box3 box;
         for (int c = 0; c < 3; c++) { box.lo[c] = (float)d->nodes[0].lo[c]; box.hi[c] = (float)d->nodes[0].hi[c]; }
+        std::vector<Job> jobs;
+        b.jobs = &jobs; b.job_depth = 6;
         b.build(0, box, all, 0);
+        b.jobs = nullptr;
+        run_jobs(b, jobs);
         align_pairs(nodes);
         b.st.nodes = nodes.size();
         b.st.refs = refs.size();
