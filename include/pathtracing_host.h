@@ -59,6 +59,10 @@ int pth_views_from_path(const char *path_file, double zoom, PtCamera *out, size_
    'l' / 'r' for the LEFT / RIGHT arrows. */
 int pth_camera_step(double eye[3], double *angle, double step, double astep, int key);
 
+/* Texture decoding as the reader does it (cv::imread(file, IMREAD_COLOR) of util/reader.cpp:67-69): baseline
+   JPEG -> BGR8.  Call with bgr == NULL to get the size; `capacity` is the size of `bgr` in bytes. */
+int pth_decode_jpeg(const char *path, int *rows, int *cols, uint8_t *bgr, size_t capacity);
+
 /* Image output (the reference only shows frames with cv::imshow). */
 int pth_write_ppm(const char *path, const uint8_t *bgr, int rows, int cols);
 int pth_write_bmp(const char *path, const uint8_t *bgr, int rows, int cols);

@@ -11,7 +11,17 @@
 // Extensions, all optional: --model main|omp (default: main, or omp with -rm as
 // that flag belongs to mainOMP.cpp), --spp N, --exact-gi (fp64 GI), --out DIR,
 // --size N, --views N (limit of -rm), --device K, --keys "wasdlr..." (camera
-// steps of simulate(), one frame per key).
+// steps of simulate(), one frame per key), --stdin (the same steps read from
+// standard input, one command per line: a key w a s d l r, "C x y z angle_deg"
+// to place the camera, q to quit; one frame per command -- simulate() of
+// main.cpp:152-189 without the window), --dataset DIR (with -rm: per view the
+// three images the reference's denoiser is trained on, DIR/<SCENE>/<SCENE>4ssp,
+// <SCENE>4096ssp and <SCENE>dif, named <scene><view>.ppm: 4 spp, 4096 spp and the
+// pass without -gi of mainOMP.cpp:263-270; --noisy-spp / --converged-spp change
+// the two counts).
+#include <cctype>
+#include <iostream>
+#include <sstream>
 #include <sys/stat.h>
 
 #include <chrono>
@@ -32,9 +42,9 @@ static int die(const char *what, const char *msg) {
 }
 
 int main(int argc, char **argv) {
-    bool gi = false, rb = false, rm = false, exact_gi = false;
-    std::string scene, model_s, out = ".", keys;
-    int spp = 0, size = 0, max_views = -1, dev = 0;
+    bool gi = false, rb = false, rm = false, exact_gi = false, from_stdin = false;
+    std::string scene, model_s, out = ".", keys, dataset;
+    int spp = 0, size = 0, max_views = -1, dev = 0, noisy_spp = 4, converged_spp = 4096;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&](const char *name) -> const char * {
@@ -53,6 +63,10 @@ int main(int argc, char **argv) {
         else if (a == "--out") out = val("--out");
         else if (a == "--keys") keys = val("--keys");
         else if (a == "--exact-gi") exact_gi = true;
+        else if (a == "--stdin") from_stdin = true;
+        else if (a == "--dataset") dataset = val("--dataset");
+        else if (a == "--noisy-spp") noisy_spp = std::atoi(val("--noisy-spp"));
+        else if (a == "--converged-spp") converged_spp = std::atoi(val("--converged-spp"));
         else if (!a.empty() && a[0] != '-') scene = a;
         else { std::fprintf(stderr, "ptmain: unknown option %s\n", a.c_str()); return 2; }
     }
@@ -108,10 +122,28 @@ int main(int argc, char **argv) {
         std::vector<PtCamera> cams(total);
         if (pth_views_from_path(pf.c_str(), cam7[6], cams.data(), total, &total)) return die("path file", pth_last_error());
         if (max_views >= 0 && (size_t)max_views < total) total = (size_t)max_views;
+        std::string upper = scene;
+        for (char &c : upper) c = (char)std::toupper((unsigned char)c);
+        if (!dataset.empty()) {
+            if (noisy_spp < 1 || converged_spp < 1) { std::fprintf(stderr, "ptmain: sample counts must be positive\n"); return 2; }
+            mkdir(dataset.c_str(), 0777);
+            mkdir((dataset + "/" + upper).c_str(), 0777);
+            for (const char *sub : {"4ssp", "4096ssp", "dif"}) mkdir((dataset + "/" + upper + "/" + upper + sub).c_str(), 0777);
+        }
         for (size_t v = 0; v < total; v++) {
             char name[64];
             std::snprintf(name, sizeof name, "/%s%zu.ppm", scene.c_str(), v);
-            if (render_one(cams[v], (uint32_t)v, out + name)) return 1;
+            if (dataset.empty()) {
+                if (render_one(cams[v], (uint32_t)v, out + name)) return 1;
+                continue;
+            }
+            const std::string base = dataset + "/" + upper + "/" + upper;
+            opt.gi = 1; opt.spp = noisy_spp;
+            if (render_one(cams[v], (uint32_t)v, base + "4ssp" + name)) return 1;
+            opt.spp = converged_spp;
+            if (render_one(cams[v], (uint32_t)v, base + "4096ssp" + name)) return 1;
+            opt.gi = 0; opt.spp = 0;
+            if (render_one(cams[v], (uint32_t)v, base + "dif" + name)) return 1;
         }
     } else {                                                    // simulate(), main.cpp:152-189
         PtCamera cam{{cam7[0], cam7[1], cam7[2]}, cam7[5], cam7[6]};
@@ -121,6 +153,27 @@ int main(int argc, char **argv) {
             char name[64];
             std::snprintf(name, sizeof name, "/%s_step%zu.ppm", scene.c_str(), k + 1);
             if (render_one(cam, 0, out + name)) return 1;
+        }
+        if (from_stdin) {
+            std::string line;
+            for (size_t k = 1; std::getline(std::cin, line); k++) {
+                std::istringstream in(line);
+                std::string cmd;
+                if (!(in >> cmd)) { k--; continue; }
+                if (cmd == "q") break;
+                if (cmd == "C") {
+                    double x, y, z, deg;
+                    if (!(in >> x >> y >> z >> deg)) return die("--stdin", "C needs x y z angle_deg");
+                    cam.eye[0] = x; cam.eye[1] = y; cam.eye[2] = z; cam.angle = deg * 0.01745329251;   // util/reader.cpp:24-29
+                } else if (cmd.size() == 1 && pth_camera_step(cam.eye, &cam.angle, cam7[3], cam7[4], cmd[0]) == 0) {
+                } else {
+                    return die("--stdin", ("unknown command '" + line + "'").c_str());
+                }
+                char name[64];
+                std::snprintf(name, sizeof name, "/%s_frame%zu.ppm", scene.c_str(), k);
+                if (render_one(cam, 0, out + name)) return 1;
+                std::fflush(stdout);
+            }
         }
     }
     pt_scene_free(ds);

@@ -145,6 +145,21 @@ int pth_camera_step(double eye[3], double *angle, double step, double astep, int
     return PT_OK;
 }
 
+int pth_decode_jpeg(const char *path, int *rows, int *cols, uint8_t *bgr, size_t capacity) {
+    if (!path || !rows || !cols) { set_error("pth_decode_jpeg: bad argument"); return PT_ERR_INVALID; }
+    pth::Texture t;
+    if (!pth::decode_jpeg_file(path, t)) {
+        set_error(std::string("pth_decode_jpeg: ") + path + " is missing or not a baseline JPEG");
+        return PT_ERR_INVALID;
+    }
+    *rows = t.rows; *cols = t.cols;
+    if (bgr) {
+        if (capacity < t.bgr.size()) { set_error("pth_decode_jpeg: buffer too small"); return PT_ERR_INVALID; }
+        std::memcpy(bgr, t.bgr.data(), t.bgr.size());
+    }
+    return PT_OK;
+}
+
 int pth_write_ppm(const char *path, const uint8_t *bgr, int rows, int cols) {
     if (!path || !bgr || rows <= 0 || cols <= 0) { set_error("pth_write_ppm: bad argument"); return PT_ERR_INVALID; }
     FILE *f = std::fopen(path, "wb");

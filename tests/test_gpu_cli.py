@@ -1,0 +1,75 @@
+"""The command-line front end (the reference's `[scene] -gi -rb -rm` surface) on a GPU: frames it writes are the
+frames the C ABI returns, for the plain run, the camera steps, the stdin protocol and the data-set triplets."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from pathtracing_amd import device, host
+
+pytestmark = pytest.mark.gpu
+PTMAIN = os.path.join(ROOT, "pathtracing_amd", "ptmain")
+
+
+def read_ppm(path):
+    data = open(path, "rb").read()
+    parts = data.split(b"\n", 3)
+    assert parts[0] == b"P6" and parts[2] == b"255"
+    w, h = (int(x) for x in parts[1].split())
+    return np.frombuffer(parts[3], np.uint8).reshape(h, w, 3)[:, :, ::-1]      # -> BGR
+
+
+def run(args, tmp, stdin=None):
+    r = subprocess.run([PTMAIN] + args + ["--out", str(tmp)], cwd=ROOT, input=stdin, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+@pytest.fixture(scope="module")
+def cbox(gpu_scenes, host_scenes):
+    return host_scenes("cbox"), gpu_scenes("cbox")
+
+
+def test_plain_run_and_camera_steps(tmp_path, cbox):
+    hs, ds = cbox
+    out = run(["cbox", "--size", "64", "--keys", "wl"], tmp_path)
+    assert "Real Triangles: 2190; Naive: 12440; Optimized: 9073" in out      # project.pdf Table 1
+    assert out.count("Elapsed time:") == 3
+    c = hs.camera()
+    want = ds.render(c["eye"], c["angle"], c["zoom"], size=64, aov=False)["bgr"]
+    assert np.array_equal(read_ppm(tmp_path / "cbox.ppm"), want)
+    eye, angle = host.camera_step(c["eye"], c["angle"], c["step"], c["astep"], "w")
+    eye, angle = host.camera_step(eye, angle, c["step"], c["astep"], "l")
+    want = ds.render(eye, angle, c["zoom"], size=64, aov=False)["bgr"]
+    assert np.array_equal(read_ppm(tmp_path / "cbox_step2.ppm"), want)
+
+
+def test_stdin_protocol(tmp_path, cbox):
+    hs, ds = cbox
+    c = hs.camera()
+    deg = c["angle"] / 0.01745329251
+    out = run(["cbox", "--size", "48", "--stdin", "-gi", "--spp", "2"], tmp_path,
+              stdin=f"d\n\nC {c['eye'][0]} {c['eye'][1]} {c['eye'][2]} {deg!r}\nq\nw\n")
+    assert out.count("Elapsed time:") == 3                                   # first frame + two commands; nothing after q
+    first, placed = read_ppm(tmp_path / "cbox.ppm"), read_ppm(tmp_path / "cbox_frame2.ppm")
+    assert np.array_equal(first, placed)                                     # "C" put the camera back where it started
+    assert not np.array_equal(first, read_ppm(tmp_path / "cbox_frame1.ppm"))
+    r = subprocess.run([PTMAIN, "cbox", "--size", "16", "--stdin", "--out", str(tmp_path)], cwd=ROOT, input="x\n",
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "unknown command" in r.stderr
+
+
+def test_dataset_triplets(tmp_path, cbox):
+    hs, ds = cbox
+    run(["cbox", "-rm", "-gi", "--views", "2", "--size", "32", "--dataset", str(tmp_path / "data"), "--noisy-spp", "1",
+         "--converged-spp", "3"], tmp_path)
+    cams = host.views_from_path(os.path.join(ROOT, "scenes", "paths", "cboxpath.txt"), hs.camera()["zoom"])
+    for v in range(2):
+        files = {k: tmp_path / "data" / "CBOX" / f"CBOX{k}" / f"cbox{v}.ppm" for k in ("4ssp", "4096ssp", "dif")}
+        cam = cams[v]
+        for k, kw in (("4ssp", dict(gi=True, spp=1)), ("4096ssp", dict(gi=True, spp=3)), ("dif", dict(gi=False))):
+            want = ds.render(list(cam.eye), cam.angle, cam.zoom, size=32, aov=False, model=device.MODEL_OMP, view=v,
+                             gi_precision=device.GI_F32_FAST, **kw)["bgr"]
+            assert np.array_equal(read_ppm(files[k]), want), (v, k)

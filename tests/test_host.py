@@ -91,6 +91,47 @@ def test_text_reader_reproduces_packed_scene(tmp_path, name):
     assert open(scene_path(name), "rb").read() == open(out, "rb").read()
 
 
+@pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="reference scene directory not present")
+@pytest.mark.parametrize("name", ["cbox", "car"])
+def test_text_reader_with_own_jpeg_decoder_reproduces_packed_scene(tmp_path, name):
+    """Same, with the reader decoding the .jpg textures itself (no decoded .ppm anywhere): the built-in decoder
+    yields the texels libjpeg-turbo yields, so the packed file is byte-identical again."""
+    sc = host.HostScene.from_dir(os.path.join(REF_SCENES, name))
+    out = tmp_path / "x.ptscene"
+    sc.save_packed(str(out))
+    assert open(scene_path(name), "rb").read() == open(out, "rb").read()
+
+
+def test_jpeg_decoder_against_fixtures(tmp_path):
+    """Baseline JPEGs of every supported kind (4:2:0 with odd sizes, 4:2:2, 4:4:4, grey, restart markers, coarse
+    quantisation, 1 x 1) decode to exactly the pixels libjpeg-turbo produced (tests/golden/make_jpeg_fixtures.py);
+    progressive files and non-JPEG data are refused, not mis-decoded."""
+    d = os.path.join(ROOT, "tests", "golden", "jpeg")
+    expected = np.load(os.path.join(d, "expected.npz"))
+    assert len(expected.files) >= 8
+    for name in expected.files:
+        got = host.decode_jpeg(os.path.join(d, name + ".jpg"))
+        assert got.shape == expected[name].shape, name
+        assert np.array_equal(got, expected[name]), (name, int(np.abs(got.astype(int) - expected[name]).max()))
+    bad = tmp_path / "bad.jpg"
+    bad.write_bytes(b"\x89PNG\r\n\x1a\n" + bytes(64))
+    with pytest.raises(host.HostError):
+        host.decode_jpeg(str(bad))
+    data = open(os.path.join(d, "c420_mcu.jpg"), "rb").read()
+    trunc = tmp_path / "trunc.jpg"
+    trunc.write_bytes(data[: len(data) // 3])                     # header intact, scan cut short: still no crash
+    try:
+        host.decode_jpeg(str(trunc))
+    except host.HostError:
+        pass
+    prog = tmp_path / "prog.jpg"
+    prog.write_bytes(data.replace(b"\xff\xc0", b"\xff\xc2", 1))  # frame marker of a progressive file
+    with pytest.raises(host.HostError):
+        host.decode_jpeg(str(prog))
+    with pytest.raises(host.HostError):
+        host.decode_jpeg(str(tmp_path / "missing.jpg"))
+
+
 def test_reader_text_format_quirks(tmp_path):
     """Record type is the LAST character of the first token; uv clamps to [0, 0.99];
     polygons are fanned; `g name 1` marks a mirror group; '%' stops the file."""
