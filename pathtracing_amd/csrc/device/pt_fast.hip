@@ -1,17 +1,18 @@
 // fp32 wavefront path for the GI sample rays (the bulk of the rays at any
 // useful sample count):
 //
-//   k_gi_gen        G-buffer + counter RNG -> compacted ray queue (SoA)
-//   k_trace_closest kd traversal, nearest hit: persistent waves, one unit of work per
-//                   lane per turn, per-lane short stack in LDS (pt_trace_f32.h)
+//   k_tile_valid/scan  once per view: where the rays of every 8x8 pixel tile start in the queue
+//   k_gi_gen        G-buffer + counter RNG -> ray queue (SoA), sorted by tile (Z curve) and
+//                   direction cell; decides in fp64 whether a ray hits the triangle it starts on
+//   k_trace_closest kd traversal, nearest hit: persistent waves, a triangle test and/or a
+//                   node step per lane per turn, per-lane ring stack in LDS (pt_trace_f32.h)
 //   k_shade_gi      surface properties + lights; OMP model: writes the sample's
 //                   contribution; MAIN model: compacts hits into a shading-point queue
 //   k_shadow_gi     MAIN model: any-hit traversal towards every light (same machinery)
 //   k_gi_sum        ordered per-pixel sum of the pass's contributions (fp64)
 //
-// Compaction between stages is a wave ballot + prefix popcount, a scan over the
-// block's waves in LDS and one atomicAdd per 1024-thread block.  Every sample owns a contribution slot, so the image does not depend
-// on the order in which waves append to or draw from the queues.
+// Every sample owns a contribution slot, so the image does not depend on the order in
+// which waves draw from the queues.
 #include <float.h>
 #include <stdlib.h>
 

@@ -6,19 +6,22 @@
 // sample rays only need the nearest hit, which no kd-tree changes -- a tree
 // decides WHICH triangles are tested, not what the nearest one is -- and on the
 // GPU the price of a tree is plain: every triangle test is three divergent
-// 16-byte loads per lane plus ~45 VALU instructions, every node step one load
+// 16-byte loads per lane plus ~30 VALU instructions, every node step one load
 // plus ~45.  The reference's tree is expensive in those terms (leaves stop as
 // soon as the centroid heuristic sees no gain, so leaves of tens to hundreds of
 // triangles are common; the split axis is fixed by depth; triangles pulled up
 // into interior nodes are tested by every ray that passes).
 //
-// Three variants, selected at upload (PT_TUNE_REFINE, for the ablation in DESIGN.md):
+// Three variants, selected at upload (PT_TUNE_REFINE; kept so that their cost can be compared):
 //   0  the host tree as it is;
 //   1  the host tree, every leaf with more than a few triangles subdivided;
 //   2  (default) a tree built from the triangles: surface-area-heuristic sweep over
 //      the triangles' clipped bounds on all three axes, empty-space bonus.
-// Measured on MI355X, closest-hit kernel, 64 spp: atrium-262k 0.91 / 1.69 / 2.6
-// Grays/s, car 2.9 / 4.8 / 7.2 Grays/s.
+// Measured on MI355X with the closest-hit kernel as it was when the variants were
+// compared, 64 spp: atrium-262k 0.91 / 1.69 / 2.6 Grays/s, car 2.9 / 4.8 / 7.2 Grays/s.
+// The build runs on up to 16 host threads (subtrees below a fixed depth are
+// independent jobs, spliced in job order, so the tree does not depend on the
+// thread count).
 #include <algorithm>
 #include <atomic>
 #include <cmath>
