@@ -476,7 +476,7 @@ struct ShadowPolicy {
     }
 };
 
-__global__ void __launch_bounds__(64) k_shadow_gi(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) k_shadow_gi(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
     extern __shared__ uint2 stack[];
     ShadowPolicy P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
     P.shadow = 0; P.fresh = false;

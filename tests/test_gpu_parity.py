@@ -147,15 +147,16 @@ def check_fast_trace(g, o):
     assert np.median(rel) < 1e-6 and np.quantile(rel, 0.999) < 3e-4, (np.median(rel), np.quantile(rel, 0.999))
 
 
-@pytest.mark.parametrize("name,model", [("cbox", 0), ("cbox", 1), ("car", 0), ("car", 1)])
-def test_fast_gi_image_close_to_exact(gpu_scenes, host_scenes, name, model):
+@pytest.mark.parametrize("name,model,rb", [("cbox", 0, False), ("cbox", 1, False), ("car", 0, False), ("car", 1, False),
+                                           ("cbox", 0, True), ("car", 1, True)])
+def test_fast_gi_image_close_to_exact(gpu_scenes, host_scenes, name, model, rb):
     """fp32 GI wavefront path vs fp64 path at equal spp and equal sample directions:
     RMSE of the linear image below 5e-4 (measured: at most 1.4e-4), fewer than 5 in 10 000 bytes of the
     8-bit frame differ (measured: below 1 in 10 000), primary outputs identical."""
     c = cam_of(host_scenes(name))
     sc = gpu_scenes(name)
-    a = sc.render(**c, model=model, gi=True, spp=8, gi_precision=device.GI_F64_EXACT)
-    b = sc.render(**c, model=model, gi=True, spp=8, gi_precision=device.GI_F32_FAST)
+    a = sc.render(**c, model=model, gi=True, rb=rb, spp=8, gi_precision=device.GI_F64_EXACT)
+    b = sc.render(**c, model=model, gi=True, rb=rb, spp=8, gi_precision=device.GI_F32_FAST)
     for k in ("mesh", "tri", "t", "gclr", "gnrm", "ghit"):
         assert np.array_equal(a[k], b[k])
     rmse = float(np.sqrt(np.mean((a["rgb"] - b["rgb"]) ** 2)))
@@ -164,7 +165,7 @@ def test_fast_gi_image_close_to_exact(gpu_scenes, host_scenes, name, model):
     assert (a["bgr"] != b["bgr"]).mean() < 5e-4
     assert a["stats"]["gi"] == b["stats"]["gi"]
     # bit-reproducible run to run (contribution slots, no float atomics)
-    b2 = sc.render(**c, model=model, gi=True, spp=8, gi_precision=device.GI_F32_FAST)
+    b2 = sc.render(**c, model=model, gi=True, rb=rb, spp=8, gi_precision=device.GI_F32_FAST)
     assert np.array_equal(b["rgb"], b2["rgb"])
 
 
