@@ -303,3 +303,20 @@ def test_full_size_atrium_properties():
         assert m["stats"]["shadow"] > 0 and m["rgb"].mean() < a["rgb"].mean()
     finally:
         ds.close()
+
+
+@pytest.mark.parametrize("size,spp", [(1, 1), (7, 3), (33, 70), (100, 200), (64, 129)])
+def test_fast_path_ragged_sizes(gpu_scenes, host_scenes, size, spp):
+    """Image sides that are not multiples of the 8-pixel tile (and not a power of two of tiles), sample counts
+    that are not multiples of the 64-sample group, several groups per pass: the fp32 path still shoots exactly the
+    rays of the fp64 path (same census) and lands on the same image."""
+    c = cam_of(host_scenes("car"))
+    sc = gpu_scenes("car")
+    for model in (0, 1):
+        e = sc.render(**c, model=model, gi=True, spp=spp, size=size, gi_precision=device.GI_F64_EXACT)
+        f = sc.render(**c, model=model, gi=True, spp=spp, size=size, gi_precision=device.GI_F32_FAST)
+        assert f["stats"]["gi"] == e["stats"]["gi"] == spp * int((e["tri"] >= 0).sum())
+        assert np.isfinite(f["rgb"]).all()
+        assert np.abs(f["rgb"] - e["rgb"]).max() < 0.05
+        assert float(np.sqrt(np.mean((f["rgb"] - e["rgb"]) ** 2))) < 2e-3
+        assert (f["bgr"] != e["bgr"]).mean() < 5e-3
