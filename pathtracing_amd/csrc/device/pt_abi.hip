@@ -50,6 +50,7 @@ struct PtScene {
     Workspace ws;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> pass_events;      // a pair per GI pass of a view (fp32 path), grown on demand
     int max_depth = 0;
     RefineStats refine;
     uint64_t dev_bytes = 0;
@@ -400,7 +401,7 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     const bool count_work = fast && (o->flags & PT_FLAG_COUNT_WORK);
     if (o->gi) {
         if (fast) {
-            rc = fast_gi(sc->S, V, F, sc->ws.Q, N, batch, s, sc->ev0, sc->ev1, gi_ms, gi_launches, &fast_rays, &fast_shadow,
+            rc = fast_gi(sc->S, V, F, sc->ws.Q, N, batch, s, sc->pass_events, gi_ms, gi_launches, &fast_rays, &fast_shadow,
                          count_work ? fast_work : nullptr);
             if (rc) return fail(rc, std::string("GI wavefront pass failed: ") + hipGetErrorString(hipGetLastError()));
         } else {
@@ -480,6 +481,7 @@ int pt_scene_free(PtScene *sc) {
     for (void *p : sc->owned) (void)hipFree(p);
     if (sc->ev0) (void)hipEventDestroy(sc->ev0);
     if (sc->ev1) (void)hipEventDestroy(sc->ev1);
+    for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
     return PT_OK;

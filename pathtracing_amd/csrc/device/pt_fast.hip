@@ -25,6 +25,7 @@
 
 #define FS_SLOTS 8                  // ring entries per lane in LDS (one of them is kept free)
 #define PT_REFILL_MIN 16             // idle lanes that trigger a refill
+#define PT_PASS_COUNT_WORDS 64       // per-pass counters, padded to a 256-byte line
 #define PT_QUEUE_CHUNK 64          // work items a wave takes from a queue head per atomicAdd
 
 // Queue append for a whole workgroup: ballot + prefix popcount inside each wave, a
@@ -489,6 +490,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
 // ---- stage 5: indirect += r1 * L over the pass's samples, in sample order ------------
 __global__ void k_gi_sum(FrameBuffers F, FastBuffers Q, int size, int nb, int first_batch) {
     size_t P = (size_t)size * size, p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0) {                                   // the pass's ray counts join the totals of the view (read once, at its end)
+        Q.totals[0] += Q.counts[0];
+        Q.totals[1] += Q.counts[2];
+    }
     if (p >= P) return;
     double ax = 0, ay = 0, az = 0;
     if (!first_batch) { ax = F.gi_acc[3 * p]; ay = F.gi_acc[3 * p + 1]; az = F.gi_acc[3 * p + 2]; }
@@ -550,8 +555,10 @@ int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *
     FA(rays_o, float4); FA(rays_d, float4); FA(ray_slot, uint32_t); FA(hits, float4);
     FA(sp_pos, float4); FA(sp_nrm, float4); FA(sp_base, float4); FA(contrib, float4);
 #undef FA
-    if ((rc = alloc(ctx, 8 * sizeof(uint32_t), (void **)&Q.counts))) return rc;
-    if ((rc = alloc(ctx, 2 * PT_HEAD_WORDS * sizeof(uint32_t), (void **)&Q.heads))) return rc;
+    // counters and queue heads of a pass in one block: one memset per pass clears them
+    if ((rc = alloc(ctx, (PT_PASS_COUNT_WORDS + 2 * PT_HEAD_WORDS) * sizeof(uint32_t), (void **)&Q.counts))) return rc;
+    Q.heads = Q.counts + PT_PASS_COUNT_WORDS;
+    if ((rc = alloc(ctx, 2 * sizeof(unsigned long long), (void **)&Q.totals))) return rc;
     if ((rc = alloc(ctx, ((pixels + 63) / 64 * 4 + 2) * sizeof(uint32_t), (void **)&Q.tile_base))) return rc;
     if ((rc = alloc(ctx, 2 * sizeof(unsigned long long), (void **)&Q.work))) return rc;
     return PT_OK;
@@ -574,38 +581,47 @@ static TraceTune trace_tune() {
 }
 
 int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers &Q, int nsamples, int batch,
-            hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow,
+            hipStream_t s, std::vector<hipEvent_t> &events, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow,
             uint64_t *work /* null, or [2]: nodes visited, triangles tested by the closest-hit launches */) {
     const int tthreads = tile_threads(V.size);
     const size_t P = (size_t)V.size * V.size;
     const TraceTune tune = trace_tune();
     *trace_ms = 0; *launches = 0; *rays = 0; *shadow = 0;
+    // The passes of a view are queued back to back; the host waits once, at the end.  A pair of events per pass
+    // times the closest-hit launches.
+    const int npass = (nsamples + batch - 1) / batch;
+    while (events.size() < 2 * (size_t)npass) {
+        hipEvent_t e;
+        FQ(hipEventCreate(&e));
+        events.push_back(e);
+    }
     if (work) FQ(hipMemsetAsync(Q.work, 0, 2 * sizeof(unsigned long long), s));
+    FQ(hipMemsetAsync(Q.totals, 0, 2 * sizeof(unsigned long long), s));
     {
         const int tiles = tthreads / 64;
         hipLaunchKernelGGL(k_tile_valid, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, s, F, Q, V.size, tiles);
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, Q, tiles);
     }
-    for (int s0 = 0; s0 < nsamples; s0 += batch) {
+    int pass = 0;
+    for (int s0 = 0; s0 < nsamples; s0 += batch, pass++) {
         int nb = nsamples - s0 < batch ? nsamples - s0 : batch;
         if ((size_t)nb * P > Q.max_rays) return PT_ERR_LIMIT;
         unsigned sblocks = (unsigned)((P * nb + PT_APPEND_BLOCK - 1) / PT_APPEND_BLOCK);
         unsigned qblocks = (unsigned)((P * nb + 63) / 64);
-        FQ(hipMemsetAsync(Q.counts, 0, 8 * sizeof(uint32_t), s));
-        FQ(hipMemsetAsync(Q.heads, 0, 2 * PT_HEAD_WORDS * sizeof(uint32_t), s));
+        FQ(hipMemsetAsync(Q.counts, 0, (PT_PASS_COUNT_WORDS + 2 * PT_HEAD_WORDS) * sizeof(uint32_t), s));
         {
             const int groups = (nb + 63) / 64;
             hipLaunchKernelGGL(k_gi_gen, dim3((unsigned)((tthreads / 64) * groups)), dim3(1024), 0, s, S, V, F, Q, s0, nb, groups);
         }
-        FQ(hipEventRecord(e0, s));
+        FQ(hipEventRecord(events[2 * pass], s));
         unsigned tblocks = qblocks < (unsigned)tune.waves ? qblocks : (unsigned)tune.waves;
         size_t lds = (size_t)tune.slots * 64 * sizeof(uint2);
-        const uint32_t chunk = (uint32_t)tune.chunk;      // smallest queue chunk (pt_persistent.h)
+        const uint32_t chunk = (uint32_t)tune.chunk;
         if (work)
             hipLaunchKernelGGL(k_trace_closest<true>, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
         else
             hipLaunchKernelGGL(k_trace_closest<false>, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
-        FQ(hipEventRecord(e1, s));
+        FQ(hipEventRecord(events[2 * pass + 1], s));
         if (V.model == PT_MODEL_MAIN) {
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(sblocks), dim3(PT_APPEND_BLOCK), 0, s, S, Q);
             hipLaunchKernelGGL(k_shadow_gi, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
@@ -614,13 +630,15 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         }
         hipLaunchKernelGGL(k_gi_sum, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, F, Q, V.size, nb, s0 == 0);
         FQ(hipGetLastError());
-        uint32_t c[8];
-        FQ(hipMemcpyAsync(c, Q.counts, sizeof c, hipMemcpyDeviceToHost, s));
-        FQ(hipStreamSynchronize(s));
+    }
+    unsigned long long tot[2];
+    FQ(hipMemcpyAsync(tot, Q.totals, sizeof tot, hipMemcpyDeviceToHost, s));
+    FQ(hipStreamSynchronize(s));
+    *rays = tot[0]; *shadow = tot[1];
+    for (int k = 0; k < npass; k++) {
         float ms = 0;
-        FQ(hipEventElapsedTime(&ms, e0, e1));
+        FQ(hipEventElapsedTime(&ms, events[2 * k], events[2 * k + 1]));
         *trace_ms += ms; (*launches)++;
-        *rays += c[0]; *shadow += c[2];
     }
     if (work) {
         unsigned long long w[2];

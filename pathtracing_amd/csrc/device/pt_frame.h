@@ -2,6 +2,7 @@
 // the C ABI layer calls.  Kernels live in pt_exact.hip (fp64, built without
 // multiply-add contraction) and pt_fast.hip (fp32 GI wavefront path).
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -51,6 +52,7 @@ struct FastBuffers {
     float4 *contrib;          // per slot: r1 * radiance of the sample ray
     uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2] shadow rays traced
     uint32_t *tile_base;      // per 8x8 tile in queue order: pixels with a primary hit before it (exclusive prefix sum; total at the end)
+    unsigned long long *totals;   // [0] GI rays, [1] shadow rays of the view so far
     uint32_t *heads;          // queue heads of the closest-hit kernel, then of the shadow kernel (pt_persistent.h)
     unsigned long long *work; // [0] nodes visited, [1] triangles tested (counting build of the closest-hit kernel)
     size_t max_rays;
@@ -77,7 +79,7 @@ int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *
 // All GI passes of one view: fills F.gi_acc.  trace_ms / launches: device time and
 // count of the closest-hit traversal launches; rays / shadow: query counts.
 int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers &Q, int nsamples, int batch,
-            hipStream_t s, hipEvent_t e0, hipEvent_t e1, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow,
+            hipStream_t s, std::vector<hipEvent_t> &events, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow,
             uint64_t *work);
 int fast_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
                int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s);
