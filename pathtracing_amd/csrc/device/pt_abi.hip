@@ -37,7 +37,7 @@ float bits_to_float(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
 struct Workspace {
     int size = 0, batch = 0, nsub = 0;
     FrameBuffers F{};
-    FastBuffers Q{};
+    FastBuffers Q[2] = {};
     SubBuffers B{};
     std::vector<void *> owned;
 };
@@ -49,6 +49,7 @@ struct PtScene {
     std::vector<void *> owned;        // device allocations of the scene
     Workspace ws;
     hipStream_t stream = nullptr;
+    hipStream_t stream_gen = nullptr;         // ray generation of the next GI pass runs here, beside the current pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> pass_events;      // a pair per GI pass of a view (fp32 path), grown on demand
     int max_depth = 0;
@@ -308,6 +309,7 @@ int upload(const PtSceneDesc *d, PtScene **out) {
         S.root_hi[k] = d->nodes[0].hi[k];
     }
     hipError_t e = hipStreamCreate(&sc->stream);
+    if (e == hipSuccess) e = hipStreamCreate(&sc->stream_gen);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev0);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
     if (e != hipSuccess) return bail(fail(PT_ERR_HIP, std::string("stream/event creation: ") + hipGetErrorString(e)));
@@ -317,7 +319,7 @@ int upload(const PtSceneDesc *d, PtScene **out) {
 
 int ensure_workspace(PtScene *sc, int size, int batch, bool fast, int nsub) {
     Workspace &ws = sc->ws;
-    bool have_fast = ws.Q.rays_o != nullptr;
+    bool have_fast = ws.Q[0].rays_o != nullptr;
     if (ws.size == size && ws.batch >= batch && (!fast || have_fast) && ws.nsub >= nsub) return PT_OK;
     if (ws.size == size) {
         if (batch < ws.batch) batch = ws.batch;
@@ -401,7 +403,7 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     const bool count_work = fast && (o->flags & PT_FLAG_COUNT_WORK);
     if (o->gi) {
         if (fast) {
-            rc = fast_gi(sc->S, V, F, sc->ws.Q, N, batch, s, sc->pass_events, gi_ms, gi_launches, &fast_rays, &fast_shadow,
+            rc = fast_gi(sc->S, V, F, sc->ws.Q, N, batch, s, sc->stream_gen, sc->pass_events, gi_ms, gi_launches, &fast_rays, &fast_shadow,
                          count_work ? fast_work : nullptr);
             if (rc) return fail(rc, std::string("GI wavefront pass failed: ") + hipGetErrorString(hipGetLastError()));
         } else {
@@ -482,6 +484,7 @@ int pt_scene_free(PtScene *sc) {
     if (sc->ev0) (void)hipEventDestroy(sc->ev0);
     if (sc->ev1) (void)hipEventDestroy(sc->ev1);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
+    if (sc->stream_gen) (void)hipStreamDestroy(sc->stream_gen);
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
     return PT_OK;

@@ -212,8 +212,6 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
                     origin_triangle_hit(S.triGeo + (size_t)otri * 9, hit, w, st[r], su[r], sv[r]))
                     rd[r].w = __uint_as_float(__float_as_uint(rd[r].w) | 0x80000000u);
                 rank[r] = atomicAdd(&hist[key[r]], 1u);
-            } else {
-                Q.contrib[(size_t)sl * P + p] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -497,7 +495,9 @@ __global__ void k_gi_sum(FrameBuffers F, FastBuffers Q, int size, int nb, int fi
     if (p >= P) return;
     double ax = 0, ay = 0, az = 0;
     if (!first_batch) { ax = F.gi_acc[3 * p]; ay = F.gi_acc[3 * p + 1]; az = F.gi_acc[3 * p + 2]; }
-    for (int s = 0; s < nb; s++) {
+    // a pixel without a primary hit shot no rays: its slots were never written (main.cpp:86 returns 0 for it)
+    const int live = F.ghit[3 * p] == -99999 ? 0 : nb;
+    for (int s = 0; s < live; s++) {
         float4 c = Q.contrib[(size_t)s * P + p];
         ax += (double)c.x; ay += (double)c.y; az += (double)c.z;
     }
@@ -546,24 +546,28 @@ __global__ void __launch_bounds__(64) k_trace_fast_f64io(DevScene S, uint32_t n,
 // ---- host side ------------------------------------------------------------------------
 #define FQ(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return PT_ERR_HIP; } while (0)
 
-int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *ctx) {
+// Two sets of ray arrays, pass counters and queue heads (Q[0], Q[1]: the generator fills one while the other is being
+// traced and shaded); the shading-point queue, the contribution slots and the per-view data are shared.
+int fast_alloc(FastBuffers Q[2], size_t pixels, int batch, PtAllocFn alloc, void *ctx) {
     size_t n = pixels * (size_t)batch;
     if (n > 0xFFFFFF00u) return PT_ERR_LIMIT;
-    Q.max_rays = n;
     int rc;
-#define FA(field, type) if ((rc = alloc(ctx, n * sizeof(type), (void **)&Q.field))) return rc
-    FA(rays_o, float4); FA(rays_d, float4); FA(ray_slot, uint32_t); FA(hits, float4);
-    FA(sp_pos, float4); FA(sp_nrm, float4); FA(sp_base, float4); FA(contrib, float4);
+#define FA(q, field, type) if ((rc = alloc(ctx, n * sizeof(type), (void **)&q.field))) return rc
+    for (int k = 0; k < 2; k++) {
+        FA(Q[k], rays_o, float4); FA(Q[k], rays_d, float4); FA(Q[k], ray_slot, uint32_t); FA(Q[k], hits, float4);
+        if ((rc = alloc(ctx, (PT_PASS_COUNT_WORDS + 2 * PT_HEAD_WORDS) * sizeof(uint32_t), (void **)&Q[k].counts))) return rc;
+        Q[k].heads = Q[k].counts + PT_PASS_COUNT_WORDS;
+        Q[k].max_rays = n;
+    }
+    FA(Q[0], sp_pos, float4); FA(Q[0], sp_nrm, float4); FA(Q[0], sp_base, float4); FA(Q[0], contrib, float4);
 #undef FA
-    // counters and queue heads of a pass in one block: one memset per pass clears them
-    if ((rc = alloc(ctx, (PT_PASS_COUNT_WORDS + 2 * PT_HEAD_WORDS) * sizeof(uint32_t), (void **)&Q.counts))) return rc;
-    Q.heads = Q.counts + PT_PASS_COUNT_WORDS;
-    if ((rc = alloc(ctx, 2 * sizeof(unsigned long long), (void **)&Q.totals))) return rc;
-    if ((rc = alloc(ctx, ((pixels + 63) / 64 * 4 + 2) * sizeof(uint32_t), (void **)&Q.tile_base))) return rc;
-    if ((rc = alloc(ctx, 2 * sizeof(unsigned long long), (void **)&Q.work))) return rc;
+    if ((rc = alloc(ctx, 2 * sizeof(unsigned long long), (void **)&Q[0].totals))) return rc;
+    if ((rc = alloc(ctx, 2 * sizeof(unsigned long long), (void **)&Q[0].work))) return rc;
+    if ((rc = alloc(ctx, ((pixels + 63) / 64 * 4 + 2) * sizeof(uint32_t), (void **)&Q[0].tile_base))) return rc;
+    Q[1].sp_pos = Q[0].sp_pos; Q[1].sp_nrm = Q[0].sp_nrm; Q[1].sp_base = Q[0].sp_base; Q[1].contrib = Q[0].contrib;
+    Q[1].totals = Q[0].totals; Q[1].work = Q[0].work; Q[1].tile_base = Q[0].tile_base;
     return PT_OK;
 }
-
 // Launch parameters of the closest-hit kernel.  The defaults are what the
 // measurements in profiles/ were taken with; the PT_TUNE_* environment
 // variables exist for sweeps.
@@ -580,40 +584,55 @@ static TraceTune trace_tune() {
     return t;
 }
 
-int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers &Q, int nsamples, int batch,
-            hipStream_t s, std::vector<hipEvent_t> &events, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow,
-            uint64_t *work /* null, or [2]: nodes visited, triangles tested by the closest-hit launches */) {
+int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers QQ[2], int nsamples, int batch,
+            hipStream_t s, hipStream_t s_gen, std::vector<hipEvent_t> &events, float *trace_ms, uint64_t *launches, uint64_t *rays,
+            uint64_t *shadow, uint64_t *work /* null, or [2]: nodes visited, triangles tested by the closest-hit launches */) {
     const int tthreads = tile_threads(V.size);
     const size_t P = (size_t)V.size * V.size;
     const TraceTune tune = trace_tune();
     *trace_ms = 0; *launches = 0; *rays = 0; *shadow = 0;
-    // The passes of a view are queued back to back; the host waits once, at the end.  A pair of events per pass
-    // times the closest-hit launches.
+    // The passes of a view are queued back to back; the host waits once, at the end.  Pass i traces, shades and sums on
+    // stream `s` out of ray set i & 1 while the generator fills the other set for pass i + 1 on stream `s_gen`.
+    // Events per pass: [4i] generation done, [4i + 1] / [4i + 2] around the closest-hit launch, [4i + 3] pass done.
     const int npass = (nsamples + batch - 1) / batch;
-    while (events.size() < 2 * (size_t)npass) {
+    while (events.size() < 4 * (size_t)npass + 1) {
         hipEvent_t e;
         FQ(hipEventCreate(&e));
         events.push_back(e);
     }
-    if (work) FQ(hipMemsetAsync(Q.work, 0, 2 * sizeof(unsigned long long), s));
-    FQ(hipMemsetAsync(Q.totals, 0, 2 * sizeof(unsigned long long), s));
+    const FastBuffers &Q0 = QQ[0];
+    if (work) FQ(hipMemsetAsync(Q0.work, 0, 2 * sizeof(unsigned long long), s));
+    FQ(hipMemsetAsync(Q0.totals, 0, 2 * sizeof(unsigned long long), s));
     {
         const int tiles = tthreads / 64;
-        hipLaunchKernelGGL(k_tile_valid, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, s, F, Q, V.size, tiles);
-        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, Q, tiles);
+        hipLaunchKernelGGL(k_tile_valid, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, s, F, Q0, V.size, tiles);
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, Q0, tiles);
     }
-    int pass = 0;
-    for (int s0 = 0; s0 < nsamples; s0 += batch, pass++) {
-        int nb = nsamples - s0 < batch ? nsamples - s0 : batch;
+    hipEvent_t view_ready = events[4 * (size_t)npass];             // G-buffer and tile offsets are in place
+    FQ(hipEventRecord(view_ready, s));
+    auto generate = [&](int pass) -> int {
+        const FastBuffers &Q = QQ[pass & 1];
+        const int s0 = pass * batch, nb = nsamples - s0 < batch ? nsamples - s0 : batch, groups = (nb + 63) / 64;
+        // the ray set is free once the pass before the previous one is done (pass 0 and 1: once the view is ready);
+        // the generator then runs beside the start of the previous pass's traversal.  (Holding it back until that
+        // traversal has ended, so that it runs beside the shading instead, was slower.)
+        FQ(hipStreamWaitEvent(s_gen, pass >= 2 ? events[4 * (pass - 2) + 3] : view_ready, 0));
+        FQ(hipMemsetAsync(Q.counts, 0, (PT_PASS_COUNT_WORDS + 2 * PT_HEAD_WORDS) * sizeof(uint32_t), s_gen));
+        hipLaunchKernelGGL(k_gi_gen, dim3((unsigned)((tthreads / 64) * groups)), dim3(1024), 0, s_gen, S, V, F, Q, s0, nb, groups);
+        FQ(hipEventRecord(events[4 * pass], s_gen));
+        return PT_OK;
+    };
+    if (int rc = generate(0)) return rc;
+    for (int pass = 0; pass < npass; pass++) {
+        const FastBuffers &Q = QQ[pass & 1];
+        const int s0 = pass * batch, nb = nsamples - s0 < batch ? nsamples - s0 : batch;
         if ((size_t)nb * P > Q.max_rays) return PT_ERR_LIMIT;
+        if (pass + 1 < npass)
+            if (int rc = generate(pass + 1)) return rc;
         unsigned sblocks = (unsigned)((P * nb + PT_APPEND_BLOCK - 1) / PT_APPEND_BLOCK);
         unsigned qblocks = (unsigned)((P * nb + 63) / 64);
-        FQ(hipMemsetAsync(Q.counts, 0, (PT_PASS_COUNT_WORDS + 2 * PT_HEAD_WORDS) * sizeof(uint32_t), s));
-        {
-            const int groups = (nb + 63) / 64;
-            hipLaunchKernelGGL(k_gi_gen, dim3((unsigned)((tthreads / 64) * groups)), dim3(1024), 0, s, S, V, F, Q, s0, nb, groups);
-        }
-        FQ(hipEventRecord(events[2 * pass], s));
+        FQ(hipStreamWaitEvent(s, events[4 * pass], 0));
+        FQ(hipEventRecord(events[4 * pass + 1], s));
         unsigned tblocks = qblocks < (unsigned)tune.waves ? qblocks : (unsigned)tune.waves;
         size_t lds = (size_t)tune.slots * 64 * sizeof(uint2);
         const uint32_t chunk = (uint32_t)tune.chunk;
@@ -621,7 +640,7 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
             hipLaunchKernelGGL(k_trace_closest<true>, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
         else
             hipLaunchKernelGGL(k_trace_closest<false>, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
-        FQ(hipEventRecord(events[2 * pass + 1], s));
+        FQ(hipEventRecord(events[4 * pass + 2], s));
         if (V.model == PT_MODEL_MAIN) {
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(sblocks), dim3(PT_APPEND_BLOCK), 0, s, S, Q);
             hipLaunchKernelGGL(k_shadow_gi, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
@@ -629,20 +648,21 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_OMP>, dim3(sblocks), dim3(PT_APPEND_BLOCK), 0, s, S, Q);
         }
         hipLaunchKernelGGL(k_gi_sum, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, F, Q, V.size, nb, s0 == 0);
+        FQ(hipEventRecord(events[4 * pass + 3], s));
         FQ(hipGetLastError());
     }
     unsigned long long tot[2];
-    FQ(hipMemcpyAsync(tot, Q.totals, sizeof tot, hipMemcpyDeviceToHost, s));
+    FQ(hipMemcpyAsync(tot, Q0.totals, sizeof tot, hipMemcpyDeviceToHost, s));
     FQ(hipStreamSynchronize(s));
     *rays = tot[0]; *shadow = tot[1];
     for (int k = 0; k < npass; k++) {
         float ms = 0;
-        FQ(hipEventElapsedTime(&ms, events[2 * k], events[2 * k + 1]));
+        FQ(hipEventElapsedTime(&ms, events[4 * k + 1], events[4 * k + 2]));
         *trace_ms += ms; (*launches)++;
     }
     if (work) {
         unsigned long long w[2];
-        FQ(hipMemcpy(w, Q.work, sizeof w, hipMemcpyDeviceToHost));
+        FQ(hipMemcpy(w, Q0.work, sizeof w, hipMemcpyDeviceToHost));
         work[0] = w[0]; work[1] = w[1];
     }
     return PT_OK;

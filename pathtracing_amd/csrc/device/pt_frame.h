@@ -75,11 +75,11 @@ int hemisphere_samples(uint32_t seed, uint32_t view, uint32_t pixel, int n, doub
 #define PT_TRACE_WAVES (256 * 32)   // waves of a trace launch: enough to fill every CU; surplus waves find the queue empty
 #define PT_FAST_RAYS_PER_PASS (16u << 20)
 typedef int (*PtAllocFn)(void *ctx, size_t bytes, void **out);
-int fast_alloc(FastBuffers &Q, size_t pixels, int batch, PtAllocFn alloc, void *ctx);
+int fast_alloc(FastBuffers Q[2], size_t pixels, int batch, PtAllocFn alloc, void *ctx);
 // All GI passes of one view: fills F.gi_acc.  trace_ms / launches: device time and
 // count of the closest-hit traversal launches; rays / shadow: query counts.
-int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers &Q, int nsamples, int batch,
-            hipStream_t s, std::vector<hipEvent_t> &events, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow,
+int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers Q[2], int nsamples, int batch,
+            hipStream_t s, hipStream_t s_gen, std::vector<hipEvent_t> &events, float *trace_ms, uint64_t *launches, uint64_t *rays, uint64_t *shadow,
             uint64_t *work);
 int fast_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
                int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s);
