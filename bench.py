@@ -52,7 +52,7 @@ def pmc_traffic(workload, rays_per_launch):
     vals = {}
     for line in open(best):
         t = line.split()
-        if len(t) >= 4 and t[-1].startswith("mean="):
+        if len(t) >= 3 and t[-1].startswith("mean="):
             vals[t[0]] = float(t[-1][5:])
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
@@ -207,6 +207,9 @@ def main():
                     "ms_per_launch_incl_warmup": round((stats.ms_gi_trace + warm.ms_gi_trace) /
                                                        max(stats.gi_trace_launches + warm.gi_trace_launches, 1), 4)}
 
+        if achieved > HBM_PEAK_GBS:
+            roofline["note"] = ("the nodes and triangles of this workload stay in L2, so its algorithmic bytes never reach HBM "
+                                "and the fraction of the HBM peak exceeds 1")
         tr = pmc_traffic(a.workload, rays_launch)
         if tr:
             roofline["traffic"], roofline["traffic_source"] = tr

@@ -1,0 +1,34 @@
+"""Host-side pieces of bench.py that need no GPU."""
+import json
+import os
+
+from conftest import ROOT
+
+
+def test_pmc_traffic_reads_the_committed_counter_summaries():
+    import bench
+    for workload in ("atrium", "car"):
+        got = bench.pmc_traffic(workload, 16777216)
+        assert got is not None, workload
+        gb, source = got
+        assert source.startswith("profiles/") and os.path.exists(os.path.join(ROOT, source))
+        assert 0.1 < gb < 100.0
+    assert bench.pmc_traffic("no-such-workload", 1) is None
+    half = bench.pmc_traffic("atrium", 8388608)[0]
+    assert abs(half - bench.pmc_traffic("atrium", 16777216)[0] / 2) < 0.02
+
+
+def test_committed_bench_lines_have_the_contract_fields():
+    for name in ("bench_default_atrium.json", "bench_default_car.json"):
+        j = json.load(open(os.path.join(ROOT, "profiles", "r01", name)))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in j, (name, k)
+        assert "workload" in j["config"] and "model" in j["config"]
+        r = j["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in r, (name, k)
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert r["traffic"] is not None
+        c = j["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
