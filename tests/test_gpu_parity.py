@@ -320,3 +320,21 @@ def test_fast_path_ragged_sizes(gpu_scenes, host_scenes, size, spp):
         assert np.abs(f["rgb"] - e["rgb"]).max() < 0.05
         assert float(np.sqrt(np.mean((f["rgb"] - e["rgb"]) ** 2))) < 2e-3
         assert (f["bgr"] != e["bgr"]).mean() < 5e-3
+
+
+@pytest.mark.parametrize("name", ["cbox", "car"])
+def test_fast_path_error_is_far_below_sampling_noise(gpu_scenes, host_scenes, name):
+    """The yardstick for a converged GI image is the noise between two independent sample sets: the fp32 path
+    must stay well inside it.  At 64 spp the RMSE between two seeds (fp64 path) is a few 1e-2; the fp32 path
+    differs from the fp64 path on the same seed by 1e-4 -- the bound asserted is a hundredth of the seed noise."""
+    c = cam_of(host_scenes(name))
+    sc = gpu_scenes(name)
+    kw = dict(model=device.MODEL_OMP, gi=True, spp=64, size=256, aov=True)
+    a = sc.render(**c, **kw, seed=0x5EED, gi_precision=device.GI_F64_EXACT)["rgb"]
+    b = sc.render(**c, **kw, seed=0xBEEF, gi_precision=device.GI_F64_EXACT)["rgb"]
+    f = sc.render(**c, **kw, seed=0x5EED, gi_precision=device.GI_F32_FAST)["rgb"]
+    noise = float(np.sqrt(np.mean((a - b) ** 2)))
+    err = float(np.sqrt(np.mean((a - f) ** 2)))
+    assert noise > 1e-3, noise                      # different seeds do give different sample sets
+    assert err < noise / 100, (err, noise)
+    assert abs(a.mean() - b.mean()) < 5e-3          # and the same expectation
