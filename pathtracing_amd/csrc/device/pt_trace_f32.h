@@ -1,14 +1,15 @@
-// fp32 kd traversal as a per-lane state machine, and the persistent-wave loop
-// that drives it.
+// fp32 kd traversal as a per-lane state machine (the persistent-wave loop that
+// drives it is in pt_persistent.h).
 //
 // Why this shape.  Rays differ a lot in length (a ray that threads a cluster of
 // fat nodes costs tens of times the mean), and the lanes of a wave are in
 // different nodes all the time.  A wave that owned 64 fixed rays and ran
 // "descend ... test leaf" loops would keep ~4 % of its lanes busy (measured).
-// Here every lane advances by ONE unit per turn of the loop -- one triangle
-// test if its current node still has untested triangles, else one node step
-// (descend / pop / restart) -- and a lane whose ray is finished takes the next
-// one from the work source.  Both unit kinds are straight-line, predicated code.
+// Here every lane advances by a unit or two per turn of the loop -- one triangle
+// test if its current node still has untested triangles, then one node step
+// (descend / pop / finish) if it has none left -- and a lane whose ray is finished
+// takes the next one from the work queue.  Both kinds of unit are straight-line,
+// predicated blocks that every lane of the wave walks through.
 //
 // Node record (16 bytes, four to a 64-byte line):
 //   split | link | tri_off | tri_end
