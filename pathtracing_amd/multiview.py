@@ -75,3 +75,30 @@ class FrameGather:
                 v = round_index * self.world + r
                 if v < n_views:
                     out[v] = self.recv[r].cpu().numpy().copy()
+
+
+def run_views(render, n_views, frame_numel, device, dist, on_frame=None):
+    """The -rm job (renderMultiple, mainOMP.cpp:225-247) over all ranks: view v is rendered by rank v % world.
+
+    render(v) -> uint8 tensor of frame_numel bytes on `device` (called only for views this rank owns);
+    on_frame(v, numpy frame) is called on rank 0 for every view, in view order within a round.
+    Works without a process group (world 1).  Returns the number of rounds."""
+    import torch
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    gather = FrameGather(frame_numel, device, dist) if world > 1 else None
+    blank = torch.zeros(frame_numel, dtype=torch.uint8, device=device)
+    n_rounds = rounds(n_views, world)
+    for k in range(n_rounds):
+        v = k * world + rank
+        frame = render(v) if v < n_views else blank
+        if world == 1:
+            if on_frame is not None:
+                on_frame(v, frame.cpu().numpy().copy())
+            continue
+        got = {} if rank == 0 else None
+        gather.gather(frame, k, n_views, got)
+        if rank == 0 and on_frame is not None:
+            for vv in sorted(got):
+                on_frame(vv, got[vv])
+    return n_rounds

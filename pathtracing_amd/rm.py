@@ -1,0 +1,101 @@
+"""The multi-view job of the reference (`mpirun ./mainOMP <scene> -gi [-rb] -rm`, mainOMP.cpp:225-247,328-354) on GPUs.
+
+    python -m pathtracing_amd.rm <scene> [-gi] [-rb] [--model omp|main] [--spp N] [--size N] [--views N] [--out DIR]
+    python -m torch.distributed.run --nproc-per-node N -m pathtracing_amd.rm <scene> -gi ...
+
+One process per GPU; rank 0 reads the scene and builds the kd-tree, the packed scene travels to the other ranks in one
+broadcast (RCCL when the backend is nccl), view v of scenes/paths/<scene>path.txt x 16 angles is rendered by rank
+v % N, and rank 0 collects the frames and writes <out>/<scene><v>.ppm.  Frames do not depend on N.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m pathtracing_amd.rm", description=__doc__.split("\n")[0])
+    ap.add_argument("scene")
+    ap.add_argument("-gi", action="store_true")
+    ap.add_argument("-rb", action="store_true")
+    ap.add_argument("--model", default="omp", choices=["main", "omp"])
+    ap.add_argument("--spp", type=int, default=0, help="0: the reference's default (16 for mainOMP, 4 for main)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--views", type=int, default=-1, help="render only the first N views of the path")
+    ap.add_argument("--out", default=".")
+    ap.add_argument("--root", default=os.getcwd(), help="directory that holds scenes/")
+    ap.add_argument("--exact-gi", action="store_true", help="fp64 GI rays (bit-identical to the CPU oracle)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: every rank on GPU 0, exchanges staged through host memory (rehearsal on a one-GPU box)")
+    a = ap.parse_args(argv)
+
+    import torch
+    import torch.distributed as dist
+    from . import device, host, multiview
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("pathtracing_amd.rm needs a GPU")
+    gpu = local_rank if a.backend == "nccl" else 0
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    xdev = dev if a.backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        dist.init_process_group(a.backend, **({"device_id": dev} if a.backend == "nccl" else {}))
+    device.init(gpu)
+
+    blob = cams = None
+    if rank == 0:
+        sdir = os.path.join(a.root, "scenes", a.scene)
+        hs = (host.HostScene.from_dir(sdir) if os.path.exists(os.path.join(sdir, "master.txt"))
+              else host.HostScene.from_packed(sdir + ".ptscene"))
+        st = hs.build_tree()
+        print(f"Real Triangles: {st['triangles']}; Naive: {st['naive']}; Optimized: {st['optimized']}")     # mainOMP.cpp:348
+        print(f"World Size: {world}")
+        views = host.views_from_path(os.path.join(a.root, "scenes", "paths", a.scene + "path.txt"), hs.camera()["zoom"])
+        cams = np.array([[*v.eye, v.angle, v.zoom] for v in views])
+        if a.views >= 0:
+            cams = cams[: a.views]
+        blob = device.scene_blob(hs.desc())
+    if world > 1:
+        blob = multiview.broadcast_bytes(blob, xdev, dist)
+        cams = multiview.broadcast_cameras(cams, xdev, dist)
+    ds = device.DeviceScene(blob=blob)
+    n = a.size
+    frame = torch.empty(n * n * 3, dtype=torch.uint8, device=dev)
+    opt = dict(gi=a.gi, rb=a.rb, model=device.MODEL_OMP if a.model == "omp" else device.MODEL_MAIN, spp=a.spp, size=n,
+               gi_precision=device.GI_F64_EXACT if a.exact_gi else device.GI_F32_FAST)
+
+    def render(v):
+        c = cams[v]
+        ds.render_to_device(device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])), frame.data_ptr(), view=v, **opt)
+        return frame if a.backend == "nccl" else frame.cpu()
+
+    t_last = [time.perf_counter()]
+
+    def on_frame(v, pixels):
+        now = time.perf_counter()
+        print(f"Elapsed time: {now - t_last[0]:g} s")                                                   # mainOMP.cpp:241
+        t_last[0] = now
+        host.write_image(os.path.join(a.out, f"{a.scene}{v}.ppm"), pixels.reshape(n, n, 3))
+
+    if rank == 0:
+        os.makedirs(a.out, exist_ok=True)
+    t0 = time.perf_counter()
+    multiview.run_views(render, len(cams), frame.numel(), xdev, dist if world > 1 else None, on_frame if rank == 0 else None)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        dt = time.perf_counter() - t0
+        print(f"{len(cams)} views on {world} GPU(s) in {dt:.3f} s: {len(cams) / dt:.2f} views/s")
+    ds.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

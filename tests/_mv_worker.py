@@ -33,12 +33,14 @@ def main():
     mine = multiview.views_of_rank(n_views, rank, world)
     owners = [None] * world
     dist.all_gather_object(owners, mine)
-    fg = multiview.FrameGather(48, dev, dist)
     got = {}
-    for k in range(multiview.rounds(n_views, world)):
-        v = k * world + rank
-        frame = torch.full((48,), (v * 7) % 251, dtype=torch.uint8) if v < n_views else torch.zeros(48, dtype=torch.uint8)
-        fg.gather(frame, k, n_views, got if rank == 0 else None)
+
+    def render(v):
+        assert v % world == rank                       # only owned views are asked for
+        return torch.full((48,), (v * 7) % 251, dtype=torch.uint8)
+
+    n_rounds = multiview.run_views(render, n_views, 48, dev, dist, (lambda v, px: got.__setitem__(v, px)) if rank == 0 else None)
+    assert n_rounds == multiview.rounds(n_views, world)
     dist.barrier()
     if rank == 0:
         ok = (len(set(digests)) == 1 and sorted(sum(owners, [])) == list(range(n_views)) and sorted(got) == list(range(n_views))

@@ -73,3 +73,28 @@ def test_dataset_triplets(tmp_path, cbox):
             want = ds.render(list(cam.eye), cam.angle, cam.zoom, size=32, aov=False, model=device.MODEL_OMP, view=v,
                              gi_precision=device.GI_F32_FAST, **kw)["bgr"]
             assert np.array_equal(read_ppm(files[k]), want), (v, k)
+
+
+def test_rm_job_frames_do_not_depend_on_the_number_of_ranks(tmp_path, cbox):
+    """`python -m pathtracing_amd.rm` (the -rm job, views dealt round-robin to ranks): one process and two processes
+    (gloo rehearsal, both ranks on this GPU) write byte-identical frames, equal to what the C ABI renders."""
+    import sys
+    hs, ds = cbox
+    args = ["cbox", "-gi", "--spp", "4", "--size", "48", "--views", "5", "--root", ROOT]
+    one, two = tmp_path / "one", tmp_path / "two"
+    r = subprocess.run([sys.executable, "-m", "pathtracing_amd.rm"] + args + ["--out", str(one)], cwd=ROOT, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Real Triangles: 2190; Naive: 12440; Optimized: 9073" in r.stdout and "World Size: 1" in r.stdout
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", "-m", "pathtracing_amd.rm"] + args +
+                       ["--out", str(two), "--backend", "gloo"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "World Size: 2" in r.stdout and r.stdout.count("Elapsed time:") == 5
+    cams = host.views_from_path(os.path.join(ROOT, "scenes", "paths", "cboxpath.txt"), hs.camera()["zoom"])
+    for v in range(5):
+        a, b = read_ppm(one / f"cbox{v}.ppm"), read_ppm(two / f"cbox{v}.ppm")
+        assert np.array_equal(a, b), v
+        want = ds.render(list(cams[v].eye), cams[v].angle, cams[v].zoom, size=48, aov=False, gi=True, spp=4,
+                         model=device.MODEL_OMP, view=v, gi_precision=device.GI_F32_FAST)["bgr"]
+        assert np.array_equal(a, want), v
