@@ -301,6 +301,10 @@ def test_full_size_atrium_properties():
         # MAIN model: shadow rays are cast, the image is darker than without shadows
         m = ds.render(**c, model=device.MODEL_MAIN, gi=True, spp=16, gi_precision=device.GI_F32_FAST)
         assert m["stats"]["shadow"] > 0 and m["rgb"].mean() < a["rgb"].mean()
+        me = ds.render(**c, model=device.MODEL_MAIN, gi=True, spp=16, gi_precision=device.GI_F64_EXACT)
+        assert float(np.sqrt(np.mean((m["rgb"] - me["rgb"]) ** 2))) < 2e-3
+        assert abs(m["rgb"].mean() - me["rgb"].mean()) < 2e-5
+        assert (m["bgr"] != me["bgr"]).mean() < 1e-3
     finally:
         ds.close()
 
