@@ -31,7 +31,8 @@ const char *pth_last_error(void);
 /* init(scene) of util/reader.cpp:10-126: reads <dir>/master.txt and the mesh
    files it names.  Textures: for a texture T the reader loads the decoded
    binary PPM (P6) "<texture_dir>/T.ppm" when texture_dir is given, else
-   "<dir>/T.ppm", else decodes "<dir>/T.jpg" when it is a baseline JPEG. */
+   "<dir>/T.ppm", else decodes "<dir>/T.jpg" when it holds a baseline JPEG or an
+   8-bit PNG (the content decides, as with cv::imread). */
 int pth_scene_load_dir(const char *dir, const char *texture_dir, PthScene **out);
 
 /* The same scene as one self-contained little-endian file ("PTSCENE1"). */
@@ -59,9 +60,10 @@ int pth_views_from_path(const char *path_file, double zoom, PtCamera *out, size_
    'l' / 'r' for the LEFT / RIGHT arrows. */
 int pth_camera_step(double eye[3], double *angle, double step, double astep, int key);
 
-/* Texture decoding as the reader does it (cv::imread(file, IMREAD_COLOR) of util/reader.cpp:67-69): baseline
-   JPEG -> BGR8.  Call with bgr == NULL to get the size; `capacity` is the size of `bgr` in bytes. */
-int pth_decode_jpeg(const char *path, int *rows, int *cols, uint8_t *bgr, size_t capacity);
+/* Texture decoding as the reader does it (cv::imread(file, IMREAD_COLOR) of util/reader.cpp:67-69): the file's
+   content decides -- baseline JPEG, or 8-bit non-interlaced PNG with its alpha channel dropped -- and the result is
+   BGR8.  Call with bgr == NULL to get the size; `capacity` is the size of `bgr` in bytes. */
+int pth_decode_image(const char *path, int *rows, int *cols, uint8_t *bgr, size_t capacity);
 
 /* Image output (the reference only shows frames with cv::imshow). */
 int pth_write_ppm(const char *path, const uint8_t *bgr, int rows, int cols);

@@ -145,16 +145,16 @@ int pth_camera_step(double eye[3], double *angle, double step, double astep, int
     return PT_OK;
 }
 
-int pth_decode_jpeg(const char *path, int *rows, int *cols, uint8_t *bgr, size_t capacity) {
-    if (!path || !rows || !cols) { set_error("pth_decode_jpeg: bad argument"); return PT_ERR_INVALID; }
+int pth_decode_image(const char *path, int *rows, int *cols, uint8_t *bgr, size_t capacity) {
+    if (!path || !rows || !cols) { set_error("pth_decode_image: bad argument"); return PT_ERR_INVALID; }
     pth::Texture t;
-    if (!pth::decode_jpeg_file(path, t)) {
-        set_error(std::string("pth_decode_jpeg: ") + path + " is missing or not a baseline JPEG");
+    if (!pth::decode_image_file(path, t)) {
+        set_error(std::string("pth_decode_image: ") + path + " is missing or neither a baseline JPEG nor an 8-bit non-interlaced PNG");
         return PT_ERR_INVALID;
     }
     *rows = t.rows; *cols = t.cols;
     if (bgr) {
-        if (capacity < t.bgr.size()) { set_error("pth_decode_jpeg: buffer too small"); return PT_ERR_INVALID; }
+        if (capacity < t.bgr.size()) { set_error("pth_decode_image: buffer too small"); return PT_ERR_INVALID; }
         std::memcpy(bgr, t.bgr.data(), t.bgr.size());
     }
     return PT_OK;

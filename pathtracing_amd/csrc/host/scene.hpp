@@ -61,6 +61,8 @@ bool load_packed(const std::string &path, Scene &out);
 bool save_packed(const Scene &scene, const std::string &path);
 bool load_ppm(const std::string &path, Texture &out);
 bool decode_jpeg_file(const std::string &path, Texture &out);   // jpeg_decode.cpp
+bool decode_png_file(const std::string &path, Texture &out);    // png_decode.cpp
+bool decode_image_file(const std::string &path, Texture &out);  // by content: JPEG or PNG, whatever the file is called
 
 // kd_build.cpp
 void flatten_geometry(const Scene &scene, Flat &flat);

@@ -47,7 +47,7 @@ bool load_texture(const std::string &dir, const std::string &texture_dir, const 
     if (!texture_dir.empty() && load_ppm(texture_dir + "/" + name + ".ppm", out)) return true;
     if (load_ppm(dir + "/" + name + ".ppm", out)) return true;
     std::string jpg = dir + "/" + name + ".jpg";
-    if (file_exists(jpg) && decode_jpeg_file(jpg, out)) return true;
+    if (file_exists(jpg) && decode_image_file(jpg, out)) return true;
     set_error("texture '" + name + "': no decoded " + name + ".ppm found and " + jpg + " could not be decoded");
     return false;
 }

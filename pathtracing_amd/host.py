@@ -69,7 +69,7 @@ def lib():
         L.pth_views_from_path.argtypes = [C.c_char_p, C.c_double, C.POINTER(PtCamera), C.c_size_t,
                                           C.POINTER(C.c_size_t)]
         L.pth_camera_step.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int]
-        L.pth_decode_jpeg.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+        L.pth_decode_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
         L.pth_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         L.pth_write_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         L.pth_scene_make_atrium.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -178,13 +178,17 @@ def camera_step(eye, angle, step, astep, key):
     return list(e), a.value
 
 
-def decode_jpeg(path):
-    """Decode a baseline JPEG the way the scene reader does: (rows, cols, 3) uint8, BGR."""
+def decode_image(path):
+    """Decode a texture file the way the scene reader does (baseline JPEG or 8-bit PNG, by content):
+    (rows, cols, 3) uint8, BGR."""
     r, c = C.c_int(), C.c_int()
-    _check(lib().pth_decode_jpeg(os.fsencode(path), C.byref(r), C.byref(c), None, 0), "pth_decode_jpeg")
+    _check(lib().pth_decode_image(os.fsencode(path), C.byref(r), C.byref(c), None, 0), "pth_decode_image")
     out = np.zeros((r.value, c.value, 3), np.uint8)
-    _check(lib().pth_decode_jpeg(os.fsencode(path), C.byref(r), C.byref(c), out.ctypes.data, out.size), "pth_decode_jpeg")
+    _check(lib().pth_decode_image(os.fsencode(path), C.byref(r), C.byref(c), out.ctypes.data, out.size), "pth_decode_image")
     return out
+
+
+decode_jpeg = decode_image
 
 
 def write_image(path, bgr):

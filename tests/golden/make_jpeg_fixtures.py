@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Small JPEG files of every kind the texture decoder accepts, with the pixels Pillow (libjpeg-turbo: slow-integer
-IDCT, fancy upsampling -- the defaults OpenCV's imread also runs with) decodes them to.
+"""Small JPEG and PNG files of every kind the texture decoder accepts, with the pixels Pillow decodes them to
+(libjpeg-turbo: slow-integer IDCT, fancy upsampling -- the defaults OpenCV's imread also runs with; PNG is lossless,
+alpha dropped as cv::imread(IMREAD_COLOR) does).
 
-    python tests/golden/make_jpeg_fixtures.py        -> tests/golden/jpeg/*.jpg, tests/golden/jpeg/expected.npz
+    python tests/golden/make_jpeg_fixtures.py        -> tests/golden/jpeg/*.jpg, *.png, tests/golden/jpeg/expected.npz
 """
 import os
 
@@ -41,5 +42,31 @@ for name, c in cases.items():
     path = os.path.join(here, name + ".jpg")
     im.save(path, format="JPEG", **c)
     expected[name] = np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1].copy()     # BGR, as cv::imread stores it
+# PNG: every colour type the decoder takes, stored / fast / best compression (stored, fixed and dynamic Huffman blocks)
+png_cases = {
+    "png_rgba": ("RGBA", dict(compress_level=9)),
+    "png_rgb": ("RGB", dict(compress_level=1)),
+    "png_grey": ("L", dict(compress_level=6)),
+    "png_greya": ("LA", dict(compress_level=9)),
+    "png_palette": ("P", dict(compress_level=9)),
+    "png_stored": ("RGB", dict(compress_level=0)),
+    "png_flat": ("RGB", dict(compress_level=9)),            # one colour: long matches, tiny dynamic trees
+}
+for name, (mode, kw) in png_cases.items():
+    img = picture(45, 37)
+    if name == "png_flat":
+        img[:] = (12, 200, 77)
+    im = Image.fromarray(img, "RGB")
+    if mode == "RGBA":
+        im.putalpha(Image.fromarray((img[:, :, 0] // 2 + 64).astype(np.uint8), "L"))
+    elif mode == "LA":
+        im = im.convert("L"); im.putalpha(Image.fromarray(img[:, :, 1], "L"))
+    elif mode == "P":
+        im = im.quantize(colors=50)
+    elif mode != "RGB":
+        im = im.convert(mode)
+    path = os.path.join(here, name + ".png")
+    im.save(path, format="PNG", **kw)
+    expected[name] = np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1].copy()
 np.savez_compressed(os.path.join(here, "expected.npz"), **expected)
 print({k: v.shape for k, v in expected.items()})

@@ -102,34 +102,46 @@ def test_text_reader_with_own_jpeg_decoder_reproduces_packed_scene(tmp_path, nam
     assert open(scene_path(name), "rb").read() == open(out, "rb").read()
 
 
-def test_jpeg_decoder_against_fixtures(tmp_path):
-    """Baseline JPEGs of every supported kind (4:2:0 with odd sizes, 4:2:2, 4:4:4, grey, restart markers, coarse
+def test_image_decoders_against_fixtures(tmp_path):
+    """PNGs of every supported colour type and deflate block kind decode to exactly Pillow's pixels (alpha dropped).
+    Baseline JPEGs of every supported kind (4:2:0 with odd sizes, 4:2:2, 4:4:4, grey, restart markers, coarse
     quantisation, 1 x 1) decode to exactly the pixels libjpeg-turbo produced (tests/golden/make_jpeg_fixtures.py);
     progressive files and non-JPEG data are refused, not mis-decoded."""
     d = os.path.join(ROOT, "tests", "golden", "jpeg")
     expected = np.load(os.path.join(d, "expected.npz"))
     assert len(expected.files) >= 8
+    assert sum(n.startswith("png_") for n in expected.files) >= 7
     for name in expected.files:
-        got = host.decode_jpeg(os.path.join(d, name + ".jpg"))
+        got = host.decode_image(os.path.join(d, name + (".png" if name.startswith("png_") else ".jpg")))
         assert got.shape == expected[name].shape, name
         assert np.array_equal(got, expected[name]), (name, int(np.abs(got.astype(int) - expected[name]).max()))
     bad = tmp_path / "bad.jpg"
     bad.write_bytes(b"\x89PNG\r\n\x1a\n" + bytes(64))
     with pytest.raises(host.HostError):
-        host.decode_jpeg(str(bad))
+        host.decode_image(str(bad))
     data = open(os.path.join(d, "c420_mcu.jpg"), "rb").read()
     trunc = tmp_path / "trunc.jpg"
     trunc.write_bytes(data[: len(data) // 3])                     # header intact, scan cut short: still no crash
     try:
-        host.decode_jpeg(str(trunc))
+        host.decode_image(str(trunc))
     except host.HostError:
         pass
     prog = tmp_path / "prog.jpg"
     prog.write_bytes(data.replace(b"\xff\xc0", b"\xff\xc2", 1))  # frame marker of a progressive file
     with pytest.raises(host.HostError):
-        host.decode_jpeg(str(prog))
+        host.decode_image(str(prog))
     with pytest.raises(host.HostError):
-        host.decode_jpeg(str(tmp_path / "missing.jpg"))
+        host.decode_image(str(tmp_path / "missing.jpg"))
+    png = open(os.path.join(d, "png_rgba.png"), "rb").read()
+    for cut in (20, len(png) // 2, len(png) - 20):                  # header only, half the pixel data, no end chunk
+        t = tmp_path / f"cut{cut}.png"
+        t.write_bytes(png[:cut])
+        with pytest.raises(host.HostError):
+            host.decode_image(str(t))
+    t = tmp_path / "sixteen.png"
+    t.write_bytes(png[:24] + bytes([16]) + png[25:])                # bit depth 16: refused
+    with pytest.raises(host.HostError):
+        host.decode_image(str(t))
 
 
 def test_reader_text_format_quirks(tmp_path):
