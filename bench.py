@@ -33,6 +33,9 @@ WORKLOADS = {
     # name: (packed scene or generator, path file, label)
     "car": ("scenes/car.ptscene", "scenes/paths/carpath.txt", "car -gi (10 264 triangles), views of scenes/paths/carpath.txt"),
     "cbox": ("scenes/cbox.ptscene", "scenes/paths/cboxpath.txt", "cbox -gi (2 190 triangles), views of scenes/paths/cboxpath.txt"),
+    # the reference ships the sponza textures, master file and camera path but not the mesh (sponza2.txt); when a
+    # complete scenes/sponza/ is supplied next to this file it is the default workload, read by the text reader as it is
+    "sponza": ("dir:scenes/sponza", "scenes/paths/sponzapath.txt", "sponza -gi, scene directory supplied by the user"),
     "atrium": (None, None, "atrium-262k -gi: procedural stand-in (262 267 triangles, seed 12345) for the sponza mesh, "
                            "which is not available; not Crytek Sponza"),
 }
@@ -61,17 +64,31 @@ def pmc_traffic(workload, rays_per_launch):
     return round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 * scale / 1e9, 2), os.path.relpath(best, ROOT)
 
 
+def default_workload():
+    """sponza when a complete scene directory has been supplied (master file and every mesh file it names), else the stand-in."""
+    d = os.path.join(ROOT, "scenes", "sponza")
+    master = os.path.join(d, "master.txt")
+    if not os.path.exists(master):
+        return "atrium"
+    meshes = [t[1] for t in (line.split() for line in open(master, errors="replace")) if len(t) >= 2 and t[0] == "O"]
+    return "sponza" if meshes and all(os.path.exists(os.path.join(d, m)) for m in meshes) else "atrium"
+
+
 def load_host_scene(name):
     from pathtracing_amd import host
     packed, path_file, _ = WORKLOADS[name]
     if packed is None:
         hs = host.HostScene.atrium(262267, 12345)
+    elif packed.startswith("dir:"):
+        hs = host.HostScene.from_dir(os.path.join(ROOT, packed[4:]))
     else:
         hs = host.HostScene.from_packed(os.path.join(ROOT, packed))
     st = hs.build_tree()
     cam = hs.camera()
-    if path_file is not None:
+    if path_file is not None and os.path.exists(os.path.join(ROOT, path_file)):
         views = list(host.views_from_path(os.path.join(ROOT, path_file), cam["zoom"]))
+    elif path_file is not None:                      # no camera path: 16 yaw angles at the scene's own camera
+        views = [host.PtCamera((C.c_double * 3)(*cam["eye"]), cam["angle"] + np.pi / 8 * j, cam["zoom"]) for j in range(16)]
     else:
         views = atrium_views(cam)
     return hs, st, views
@@ -94,7 +111,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=os.environ.get("PT_BENCH_WORKLOAD", "atrium"), choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=os.environ.get("PT_BENCH_WORKLOAD", default_workload()), choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=1024, help="GI samples per pixel (the reference's converged sponza/room renders use 1024)")
     ap.add_argument("--model", default="omp", choices=["main", "omp"])
     ap.add_argument("--rb", action="store_true")
@@ -219,7 +236,7 @@ def main():
             from oracle import ptoracle as po
             packed = WORKLOADS[a.workload][0]
             tmp = None
-            if packed is None:
+            if packed is None or packed.startswith("dir:"):
                 tmp = os.path.join("/tmp", f"bench_{a.workload}_{os.getpid()}.ptscene")
                 hs.save_packed(tmp)
                 packed_path = tmp
@@ -251,7 +268,7 @@ def main():
             "ms_per_step": round(dt_max / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (GI sample rays) + f64 (primary, mirror, their shadow rays)",
-            "data": "synthetic" if a.workload == "atrium" else "reference scene file, packed",
+            "data": "synthetic" if a.workload == "atrium" else ("scene directory supplied by the user" if a.workload == "sponza" else "reference scene file, packed"),
             "config": {"workload": WORKLOADS[a.workload][2], "spp": a.spp, "model": a.model, "rb": bool(a.rb),
                        "image": "512x512", "views_per_step": world, "parallelism": f"views round-robin over {world} GPU(s)",
                        "triangles": st["triangles"], "kd_refs": st["optimized"], "kd_nodes": st["nodes"],

@@ -32,3 +32,25 @@ def test_committed_bench_lines_have_the_contract_fields():
         assert r["traffic"] is not None
         c = j["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_supplied_sponza_directory_becomes_the_default_workload(tmp_path, monkeypatch):
+    """bench.py runs the stand-in only while scenes/sponza/ is incomplete (the reference ships no sponza mesh): a
+    directory with master.txt and every mesh it names is picked up and read by the text reader."""
+    import shutil
+
+    import pytest
+
+    import bench
+    assert bench.default_workload() == "atrium"                      # nothing supplied in this repository
+    ref = "/root/reference/scenes/cbox"
+    if not os.path.isdir(ref):
+        pytest.skip("reference scene directory not present")
+    root = tmp_path / "root"
+    shutil.copytree(ref, root / "scenes" / "sponza")                 # any complete scene directory will do
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    assert bench.default_workload() == "sponza"
+    hs, st, views = bench.load_host_scene("sponza")
+    assert st["triangles"] == 2190 and len(views) == 16              # no camera path supplied: 16 angles at the scene camera
+    os.remove(root / "scenes" / "sponza" / "cbox2.txt")
+    assert bench.default_workload() == "atrium"                      # mesh missing again
