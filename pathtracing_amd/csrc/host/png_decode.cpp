@@ -33,12 +33,20 @@ struct Bits {
         return v;
     }
     void align() { acc = 0; n = 0; }
+    // the next k bits without consuming them (zero-padded past the end); k <= 16
+    uint32_t peek(int k) {
+        while (n < k && p < end) { acc |= (uint32_t)*p++ << n; n += 8; }
+        return acc & ((1u << k) - 1u);
+    }
+    void skip(int k) { acc >>= k; n -= k; }
 };
 
 // Canonical Huffman code over `count` symbols with the given code lengths (deflate, RFC 1951 section 3.2.2).
 struct Code {
+    static constexpr int FAST = 10;        // codes of up to FAST bits are looked up in one step
     uint16_t first[16], offset[16], nlen[16];
     std::vector<uint16_t> symbols;
+    uint16_t fast[1 << FAST];              // symbol << 4 | length, indexed by the next FAST bits of the stream; 0: longer code
     bool build(const uint8_t *lengths, int count) {
         std::memset(nlen, 0, sizeof nlen);
         for (int i = 0; i < count; i++) nlen[lengths[i]]++;
@@ -54,11 +62,29 @@ struct Code {
         symbols.assign(total, 0);
         uint16_t next[16];
         std::memcpy(next, offset, sizeof next);
-        for (int i = 0; i < count; i++)
-            if (lengths[i]) symbols[next[lengths[i]]++] = (uint16_t)i;
+        std::memset(fast, 0, sizeof fast);
+        uint16_t nextcode[16];
+        std::memcpy(nextcode, first, sizeof nextcode);
+        for (int i = 0; i < count; i++) {
+            const int len = lengths[i];
+            if (!len) continue;
+            symbols[next[len]++] = (uint16_t)i;
+            const uint32_t c = nextcode[len]++;
+            if (len <= FAST) {
+                uint32_t rev = 0;                                     // the stream carries a code most significant bit first
+                for (int k = 0; k < len; k++) rev |= ((c >> k) & 1u) << (len - 1 - k);
+                for (uint32_t fill = rev; fill < (1u << FAST); fill += 1u << len) fast[fill] = (uint16_t)((i << 4) | len);
+            }
+        }
         return true;
     }
     int decode(Bits &b) const {
+        const uint16_t f = fast[b.peek(FAST)];
+        if (f) {
+            if ((f & 15) > b.n) { b.bad = true; return -1; }
+            b.skip(f & 15);
+            return f >> 4;
+        }
         uint32_t code = 0;
         for (int len = 1; len < 16; len++) {
             code = (code << 1) | b.get(1);
