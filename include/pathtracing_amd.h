@@ -92,6 +92,11 @@ typedef struct PtOptions {
     uint32_t view;            /* second key word: index of the view in a multi-view job */
     int32_t size;             /* image rows = cols; 0 = 512 (main.cpp:14) */
     uint32_t flags;           /* PT_FLAG_* */
+    uint32_t part, n_parts;   /* one view split over n_parts workers: this call renders only the 8-row bands b
+                                 with b % n_parts == part -- renderParallel() deals the rows of a view round-robin
+                                 to its workers (mainOMP.cpp:169-174); here the unit is a band of 8 rows, the
+                                 height of the device's pixel tiles.  Every other row of every output is zero
+                                 (AOV ids -1).  n_parts 0 or 1: the whole view. */
 } PtOptions;
 
 /* Count the nodes visited and triangles tested by the GI closest-hit kernel

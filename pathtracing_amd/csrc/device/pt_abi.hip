@@ -361,6 +361,7 @@ int check_options(const PtOptions *o, int *size, int *nsamples) {
     if (o->model != PT_MODEL_MAIN && o->model != PT_MODEL_OMP) return fail(PT_ERR_INVALID, "unknown shading model");
     if (o->gi_precision != PT_GI_F64_EXACT && o->gi_precision != PT_GI_F32_FAST) return fail(PT_ERR_INVALID, "unknown gi_precision");
     if (o->spp < 0) return fail(PT_ERR_INVALID, "spp is negative");
+    if (o->n_parts > 1 && o->part >= o->n_parts) return fail(PT_ERR_INVALID, "part must be below n_parts");
     int s = o->size == 0 ? 512 : o->size;
     if (s < 1 || s > 8192) return fail(PT_ERR_LIMIT, "image size must be in 1..8192");
     *size = s;
@@ -395,6 +396,7 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     V.size = size; V.rb = o->rb ? 1 : 0;
     V.off = o->model == PT_MODEL_MAIN ? 0.01 : 0.1;
     V.seed = o->seed; V.view = o->view; V.model = o->model;
+    V.part = o->n_parts > 1 ? o->part : 0; V.n_parts = o->n_parts > 1 ? o->n_parts : 1;
     hipStream_t s = sc->stream;
     HIPCHK(hipMemsetAsync(F.counters, 0, RC_N * sizeof(unsigned long long), s));
     if (exact_primary(sc->S, V, F, sc->ws.B, s)) return fail(PT_ERR_HIP, "primary pass launch failed");

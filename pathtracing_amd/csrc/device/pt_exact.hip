@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(64) k_primary_exact(DevScene S, ViewParams V, 
         lin = blockIdx.x * 64u + lane;
     }
     int i = 0, j = 0;
-    live = live && tile_pixel((int)lin, V.size, i, j);
+    live = live && tile_pixel((int)lin, V.size, i, j) && own_row(V.part, V.n_parts, i);
     if (live) {
         const size_t p = (size_t)i * V.size + j, slot = V.rb ? p * 9 + sub : p;
         // the offsets as the reference's loops produce them: -o, -o + o, (-o + o) + o  (main.cpp:116-117)
@@ -76,10 +76,20 @@ __global__ void __launch_bounds__(64) k_primary_exact(DevScene S, ViewParams V, 
 // Sum of the sub-rays in the reference's order, /9 for a bundle (main.cpp:122-125).  G-buffer owner:
 // MAIN -- every sub-ray writes, the last wins, a miss only writes mhit (main.cpp:44-47,68-70);
 // OMP -- the centre ray only (mainOMP.cpp:124-127).
+// A pixel of a row that another worker renders gets the record of a ray that was never shot:
+// black, and the G-buffer mark that keeps the GI pass away from it.
 template <int MODEL>
-__global__ void k_primary_combine(FrameBuffers F, SubBuffers B, int size, int rb) {
+__global__ void k_primary_combine(FrameBuffers F, SubBuffers B, int size, int rb, uint32_t part, uint32_t n_parts) {
     size_t P = (size_t)size * size, p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
+    if (!own_row(part, n_parts, (int)(p / size))) {
+        const D3 zero = d3(0, 0, 0);
+        dstore(F.mpnt + 3 * p, zero);
+        dstore(F.gclr + 3 * p, zero); dstore(F.gnrm + 3 * p, zero); dstore(F.ghit + 3 * p, d3(-99999, -99999, -99999));
+        F.rec_found[p] = 0; F.rec_tri[p] = -1;
+        F.rec_t[p] = 0; F.rec_u[p] = 0; F.rec_v[p] = 0;
+        return;
+    }
     const int nsub = rb ? 9 : 1;
     D3 paint = d3(0, 0, 0), clr = d3(0, 0, 0), nrm = d3(0, 0, 0), hit = d3(0, 0, 0);
     size_t owner = p * nsub;
@@ -195,10 +205,10 @@ int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F,
     const unsigned blocks = V.rb ? (unsigned)(((size_t)tile_threads(V.size) * 9 + 62) / 63) : (unsigned)(tile_threads(V.size) / 64);
     if (V.model == PT_MODEL_MAIN) {
         hipLaunchKernelGGL(k_primary_exact<PT_MODEL_MAIN>, dim3(blocks), dim3(64), 0, s, S, V, F, B);
-        hipLaunchKernelGGL(k_primary_combine<PT_MODEL_MAIN>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb);
+        hipLaunchKernelGGL(k_primary_combine<PT_MODEL_MAIN>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb, V.part, V.n_parts);
     } else {
         hipLaunchKernelGGL(k_primary_exact<PT_MODEL_OMP>, dim3(blocks), dim3(64), 0, s, S, V, F, B);
-        hipLaunchKernelGGL(k_primary_combine<PT_MODEL_OMP>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb);
+        hipLaunchKernelGGL(k_primary_combine<PT_MODEL_OMP>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb, V.part, V.n_parts);
     }
     return LAUNCH_OK();
 }

@@ -383,8 +383,20 @@ __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBu
             float ar, ag, ab;
             SurfF sf = surface_f(S, tri, h.y, h.z, ar, ag, ab);
             ar *= sf.tr; ag *= sf.tg; ab *= sf.tb;
-            float hx = o.x + h.x * d.x + 0.0001f * sf.nx, hy = o.y + h.x * d.y + 0.0001f * sf.ny,
-                  hz = o.z + h.x * d.z + 0.0001f * sf.nz;
+            float hx, hy, hz;
+            if (MODEL == PT_MODEL_OMP) {
+                hx = o.x + h.x * d.x + 0.0001f * sf.nx; hy = o.y + h.x * d.y + 0.0001f * sf.ny; hz = o.z + h.x * d.z + 0.0001f * sf.nz;
+            } else {
+                // Shadow rays start here, 1e-4 off the surface (main.cpp:50), and that step has to survive: o + t d in fp32
+                // is off by t * 2^-24, more than 1e-4 for a ray a few thousand units long, and puts the point behind a
+                // second triangle lying in the same plane (two-sided leaves are modelled that way), which then shadows it.
+                // The point is taken from the triangle instead, v0 + u e1 + v e2 in fp64, and rounded once.
+                const double *T9 = S.triGeo + (size_t)tri * 9;
+                const double bu = (double)h.y, bv = (double)h.z;
+                hx = (float)(T9[0] + bu * T9[3] + bv * T9[6] + 1e-4 * (double)sf.nx);
+                hy = (float)(T9[1] + bu * T9[4] + bv * T9[7] + 1e-4 * (double)sf.ny);
+                hz = (float)(T9[2] + bu * T9[5] + bv * T9[8] + 1e-4 * (double)sf.nz);
+            }
             if (MODEL == PT_MODEL_OMP) {
                 // mainOMP.cpp:55-62,74-75: every light is visible; r1 * txt*albedo*direct/pi
                 float dr = 0, dg = 0, db = 0;

@@ -16,7 +16,13 @@ struct ViewParams {
     double off;               // bundle offset: 0.01 (main.cpp:116) or 0.1 (mainOMP.cpp:117)
     uint32_t seed, view;
     int32_t model;
+    uint32_t part, n_parts;   // rows of this call: 8-row bands b with b % n_parts == part (n_parts >= 1)
 };
+
+// Does image row i belong to this call?
+__host__ __device__ inline bool own_row(uint32_t part, uint32_t n_parts, int i) {
+    return n_parts <= 1u || ((uint32_t)i >> 3) % n_parts == part;
+}
 
 struct FrameBuffers {
     double *mpnt;             // 3 per pixel: direct pass result, main.cpp:31

@@ -20,7 +20,7 @@ FLT_MAX = float(np.finfo(np.float32).max)
 class PtOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("gi", C.c_int32), ("rb", C.c_int32), ("model", C.c_int32),
                 ("spp", C.c_int32), ("gi_precision", C.c_int32), ("seed", C.c_uint32), ("view", C.c_uint32),
-                ("size", C.c_int32), ("flags", C.c_uint32)]
+                ("size", C.c_int32), ("flags", C.c_uint32), ("part", C.c_uint32), ("n_parts", C.c_uint32)]
 
 
 class PtAov(C.Structure):
@@ -98,8 +98,8 @@ FLAG_COUNT_WORK = 1
 
 
 def make_options(gi=False, rb=False, model=MODEL_MAIN, spp=0, gi_precision=GI_F64_EXACT, seed=0x5EED, view=0, size=512,
-                 flags=0):
-    return PtOptions(C.sizeof(PtOptions), int(gi), int(rb), model, spp, gi_precision, seed, view, size, flags)
+                 flags=0, part=0, n_parts=0):
+    return PtOptions(C.sizeof(PtOptions), int(gi), int(rb), model, spp, gi_precision, seed, view, size, flags, part, n_parts)
 
 
 def scene_blob(desc):

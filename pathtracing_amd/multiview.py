@@ -11,6 +11,12 @@ remain are
   packed scene blob (RCCL over xGMI when the tensors live on GPUs);
 * per round of views: the finished BGR8 frames are gathered on rank 0.
 
+A second mode splits every single view over all ranks (run_split_views): the
+reference's own distribution, rows of one view dealt round-robin to the workers
+(mainOMP.cpp:169-174), for when the time to the next frame matters more than
+frames per second.  The unit is a band of 8 rows, the height of the device's
+pixel tiles; per view, every rank sends only its own bands to rank 0.
+
 torch.distributed is plumbing only; with the "gloo" backend and CPU tensors the
 same code runs without a GPU, which is how the tests cover it.
 """
@@ -102,3 +108,59 @@ def run_views(render, n_views, frame_numel, device, dist, on_frame=None):
             for vv in sorted(got):
                 on_frame(vv, got[vv])
     return n_rounds
+
+
+BAND_ROWS = 8       # rows per band of the row split: PtOptions.part / n_parts count bands of this height
+
+
+def bands_of_rank(size, rank, world):
+    """Row bands of a size x size frame owned by `rank`: band b (rows 8b .. 8b+7) goes to rank b % world."""
+    return list(range(rank, (size + BAND_ROWS - 1) // BAND_ROWS, world))
+
+
+class BandGather:
+    """Collects on rank 0 the row bands that every rank rendered of ONE view and interleaves them into the frame."""
+
+    def __init__(self, size, device, dist):
+        import torch
+        self.torch, self.dist, self.size = torch, dist, size
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.n_bands = (size + BAND_ROWS - 1) // BAND_ROWS
+        self.band_bytes = BAND_ROWS * size * 3
+        self.share = (self.n_bands + self.world - 1) // self.world          # bands per rank, the last ranks may own one fewer
+        self.padded = torch.zeros(self.n_bands * self.band_bytes, dtype=torch.uint8, device=device)
+        self.send = torch.zeros(self.share * self.band_bytes, dtype=torch.uint8, device=device)
+        self.recv = ([torch.empty_like(self.send) for _ in range(self.world)] if self.rank == 0 else None)
+
+    def gather(self, frame):
+        """frame: uint8 tensor of size*size*3 bytes whose own bands are rendered.  Returns the whole frame (numpy) on rank 0."""
+        n = self.size * self.size * 3
+        self.padded[:n] = frame
+        mine = self.padded.view(self.n_bands, self.band_bytes)[self.rank::self.world]
+        self.send.view(self.share, self.band_bytes)[: mine.shape[0]] = mine
+        self.dist.gather(self.send, self.recv, dst=0)
+        if self.rank != 0:
+            return None
+        whole = self.padded.view(self.n_bands, self.band_bytes)
+        for r in range(self.world):
+            k = len(range(r, self.n_bands, self.world))
+            whole[r::self.world] = self.recv[r].view(self.share, self.band_bytes)[:k]
+        return self.padded[:n].cpu().numpy().copy()
+
+
+def run_split_views(render_part, n_views, size, device, dist, on_frame=None):
+    """Every view rendered by all ranks together, rank r the row bands b with b % world == r (renderParallel's
+    row dealing, mainOMP.cpp:169-174, in bands of 8 rows).
+
+    render_part(v, part, n_parts) -> uint8 tensor of size*size*3 bytes on `device`, rows outside the part's bands
+    unspecified; on_frame(v, numpy frame) is called on rank 0 for every view in order.  Works without a process
+    group (world 1).  Returns the number of views."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    gather = BandGather(size, device, dist) if world > 1 else None
+    for v in range(n_views):
+        frame = render_part(v, rank, world)
+        whole = gather.gather(frame) if world > 1 else frame.cpu().numpy().copy()
+        if rank == 0 and on_frame is not None:
+            on_frame(v, whole)
+    return n_views

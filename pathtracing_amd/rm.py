@@ -1,11 +1,13 @@
 """The multi-view job of the reference (`mpirun ./mainOMP <scene> -gi [-rb] -rm`, mainOMP.cpp:225-247,328-354) on GPUs.
 
-    python -m pathtracing_amd.rm <scene> [-gi] [-rb] [--model omp|main] [--spp N] [--size N] [--views N] [--out DIR]
+    python -m pathtracing_amd.rm <scene> [-gi] [-rb] [--model omp|main] [--spp N] [--size N] [--views N] [--out DIR] [--split-rows]
     python -m torch.distributed.run --nproc-per-node N -m pathtracing_amd.rm <scene> -gi ...
 
 One process per GPU; rank 0 reads the scene and builds the kd-tree, the packed scene travels to the other ranks in one
 broadcast (RCCL when the backend is nccl), view v of scenes/paths/<scene>path.txt x 16 angles is rendered by rank
 v % N, and rank 0 collects the frames and writes <out>/<scene><v>.ppm.  Frames do not depend on N.
+With --split-rows every view is rendered by all N GPUs together instead, each the 8-row bands b with b % N == rank
+(the reference's own dealing of rows to its workers, mainOMP.cpp:169-174): same frames, shorter time to each frame.
 """
 import argparse
 import os
@@ -26,6 +28,7 @@ def main(argv=None):
     ap.add_argument("--views", type=int, default=-1, help="render only the first N views of the path")
     ap.add_argument("--out", default=".")
     ap.add_argument("--root", default=os.getcwd(), help="directory that holds scenes/")
+    ap.add_argument("--split-rows", action="store_true", help="all GPUs share every view (bands of 8 rows) instead of one view each")
     ap.add_argument("--exact-gi", action="store_true", help="fp64 GI rays (bit-identical to the CPU oracle)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: every rank on GPU 0, exchanges staged through host memory (rehearsal on a one-GPU box)")
@@ -69,9 +72,10 @@ def main(argv=None):
     opt = dict(gi=a.gi, rb=a.rb, model=device.MODEL_OMP if a.model == "omp" else device.MODEL_MAIN, spp=a.spp, size=n,
                gi_precision=device.GI_F64_EXACT if a.exact_gi else device.GI_F32_FAST)
 
-    def render(v):
+    def render(v, part=0, n_parts=0):
         c = cams[v]
-        ds.render_to_device(device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])), frame.data_ptr(), view=v, **opt)
+        ds.render_to_device(device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])), frame.data_ptr(), view=v,
+                            part=part, n_parts=n_parts, **opt)
         return frame if a.backend == "nccl" else frame.cpu()
 
     t_last = [time.perf_counter()]
@@ -85,7 +89,10 @@ def main(argv=None):
     if rank == 0:
         os.makedirs(a.out, exist_ok=True)
     t0 = time.perf_counter()
-    multiview.run_views(render, len(cams), frame.numel(), xdev, dist if world > 1 else None, on_frame if rank == 0 else None)
+    if a.split_rows:
+        multiview.run_split_views(render, len(cams), n, xdev, dist if world > 1 else None, on_frame if rank == 0 else None)
+    else:
+        multiview.run_views(render, len(cams), frame.numel(), xdev, dist if world > 1 else None, on_frame if rank == 0 else None)
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -41,9 +41,27 @@ def main():
 
     n_rounds = multiview.run_views(render, n_views, 48, dev, dist, (lambda v, px: got.__setitem__(v, px)) if rank == 0 else None)
     assert n_rounds == multiview.rounds(n_views, world)
+    # one view split over the ranks by row bands; sizes that are not multiples of 8 rows or of the world size
+    split_ok = True
+    for size in (20, 64, 9):
+        def pattern(v):
+            return ((np.arange(size * size * 3, dtype=np.int64) * 31 + v * 17) % 253).astype(np.uint8).reshape(size, size * 3)
+
+        def render_part(v, part, n_parts, size=size, pattern=pattern):
+            assert (part, n_parts) == (rank, world)
+            full = pattern(v)
+            f = np.full_like(full, 255)                # rows of other ranks hold junk that must not reach the frame
+            for b in multiview.bands_of_rank(size, part, n_parts):
+                f[8 * b: 8 * b + 8] = full[8 * b: 8 * b + 8]
+            return torch.from_numpy(f.reshape(-1))
+
+        whole = {}
+        multiview.run_split_views(render_part, 3, size, dev, dist, (lambda v, px: whole.__setitem__(v, px)) if rank == 0 else None)
+        if rank == 0:
+            split_ok = split_ok and sorted(whole) == [0, 1, 2] and all((whole[v].reshape(size, size * 3) == pattern(v)).all() for v in whole)
     dist.barrier()
     if rank == 0:
-        ok = (len(set(digests)) == 1 and sorted(sum(owners, [])) == list(range(n_views)) and sorted(got) == list(range(n_views))
+        ok = (split_ok and len(set(digests)) == 1 and sorted(sum(owners, [])) == list(range(n_views)) and sorted(got) == list(range(n_views))
               and all((got[v] == (v * 7) % 251).all() for v in got))
         print(json.dumps({"ok": bool(ok), "world": world, "views": n_views, "blob_bytes": int(blob.size),
                           "max_share": max(len(o) for o in owners), "min_share": min(len(o) for o in owners)}))

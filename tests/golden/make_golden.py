@@ -32,7 +32,7 @@ def sha(a):
 
 
 def main():
-    for name in ("cbox", "car"):
+    for name in ("cbox", "car", "pine"):
         s = po.OracleScene(os.path.join(ROOT, "scenes", name + ".ptscene"))
         r = s.render(model=po.MODEL_MAIN, threads=8, brute=True)
         deg = (r["mesh"] != r["bmesh"]) | (r["tri"] != r["btri"])

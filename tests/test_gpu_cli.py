@@ -91,10 +91,18 @@ def test_rm_job_frames_do_not_depend_on_the_number_of_ranks(tmp_path, cbox):
                        ["--out", str(two), "--backend", "gloo"], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "World Size: 2" in r.stdout and r.stdout.count("Elapsed time:") == 5
+    # latency mode: both ranks share every view, bands of 8 rows dealt round-robin (48 rows = 6 bands)
+    split = tmp_path / "split"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29534", "-m", "pathtracing_amd.rm"] + args +
+                       ["--out", str(split), "--backend", "gloo", "--split-rows"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("Elapsed time:") == 5
     cams = host.views_from_path(os.path.join(ROOT, "scenes", "paths", "cboxpath.txt"), hs.camera()["zoom"])
     for v in range(5):
         a, b = read_ppm(one / f"cbox{v}.ppm"), read_ppm(two / f"cbox{v}.ppm")
         assert np.array_equal(a, b), v
+        assert np.array_equal(a, read_ppm(split / f"cbox{v}.ppm")), v
         want = ds.render(list(cams[v].eye), cams[v].angle, cams[v].zoom, size=48, aov=False, gi=True, spp=4,
                          model=device.MODEL_OMP, view=v, gi_precision=device.GI_F32_FAST)["bgr"]
         assert np.array_equal(a, want), v

@@ -46,7 +46,7 @@ def test_hemisphere_samples_bit_exact(gpu_scenes):
         assert np.array_equal(device.hemisphere_samples(seed, view, pixel, 4096), po.hemisphere_samples(seed, view, pixel, 4096))
 
 
-@pytest.mark.parametrize("name", ["cbox", "car"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
 def test_direct_frame_bit_exact_main(gpu_scenes, oracle_scenes, host_scenes, name):
     """config 1 (cbox direct, main.cpp model) and the same for car: every output bit for bit."""
     c = cam_of(host_scenes(name))
@@ -60,7 +60,7 @@ def test_direct_frame_bit_exact_main(gpu_scenes, oracle_scenes, host_scenes, nam
 
 
 @pytest.mark.parametrize("name,model,rb", [("cbox", 0, False), ("cbox", 0, True), ("cbox", 1, False), ("cbox", 1, True),
-                                           ("car", 0, False), ("car", 1, False)])
+                                           ("car", 0, False), ("car", 1, False), ("pine", 0, True), ("pine", 1, False)])
 def test_gi_frame_bit_exact(gpu_scenes, oracle_scenes, host_scenes, name, model, rb):
     """-gi (and -gi -rb) with the counter RNG: the fp64 path reproduces the oracle image exactly."""
     c = cam_of(host_scenes(name))
@@ -110,7 +110,7 @@ def random_rays(n, seed, box):
     return src, d
 
 
-@pytest.mark.parametrize("name", ["cbox", "car"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
 def test_trace_random_rays_bit_exact(gpu_scenes, oracle_scenes, name):
     """pt_trace mode 0 == search() of the reference on incoherent rays, closest-hit and bounded."""
     s = oracle_scenes(name)
@@ -123,7 +123,7 @@ def test_trace_random_rays_bit_exact(gpu_scenes, oracle_scenes, name):
     assert gpu_scenes(name).trace(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0))["found"].size == 0
 
 
-@pytest.mark.parametrize("name", ["cbox", "car"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
 def test_fast_trace_against_brute_force(gpu_scenes, oracle_scenes, name):
     """pt_trace mode 1 (fp32 kd traversal, the GI fast path) finds the true nearest hit:
     same triangle as an fp64 brute force wherever the two nearest candidates are not
@@ -148,25 +148,68 @@ def check_fast_trace(g, o):
 
 
 @pytest.mark.parametrize("name,model,rb", [("cbox", 0, False), ("cbox", 1, False), ("car", 0, False), ("car", 1, False),
-                                           ("cbox", 0, True), ("car", 1, True)])
+                                           ("cbox", 0, True), ("car", 1, True), ("pine", 0, False), ("pine", 1, True)])
 def test_fast_gi_image_close_to_exact(gpu_scenes, host_scenes, name, model, rb):
-    """fp32 GI wavefront path vs fp64 path at equal spp and equal sample directions:
-    RMSE of the linear image below 5e-4 (measured: at most 1.4e-4), fewer than 5 in 10 000 bytes of the
-    8-bit frame differ (measured: below 1 in 10 000), primary outputs identical."""
+    """fp32 GI wavefront path vs fp64 path at equal spp and equal sample directions.  A handful of the 2 M sample
+    rays end on another triangle (the reference search is not always a nearest-hit search, and fp32 may pick the
+    other of two near-equal candidates): at most 30 of the 262 144 pixels may differ by more than 0.01 (measured:
+    at most 5; one such sample moves a pixel of the brightly lit pine scene by 0.3), the RMSE over all other pixels
+    is below 2e-4 (measured: at most 1.4e-4), fewer than 5 in 10 000 bytes of the 8-bit frame differ (measured:
+    below 1 in 10 000), primary outputs identical."""
     c = cam_of(host_scenes(name))
     sc = gpu_scenes(name)
     a = sc.render(**c, model=model, gi=True, rb=rb, spp=8, gi_precision=device.GI_F64_EXACT)
     b = sc.render(**c, model=model, gi=True, rb=rb, spp=8, gi_precision=device.GI_F32_FAST)
     for k in ("mesh", "tri", "t", "gclr", "gnrm", "ghit"):
         assert np.array_equal(a[k], b[k])
-    rmse = float(np.sqrt(np.mean((a["rgb"] - b["rgb"]) ** 2)))
-    assert rmse < 5e-4, rmse
-    assert abs(a["rgb"].mean() - b["rgb"].mean()) < 5e-6
+    d = a["rgb"] - b["rgb"]
+    outlier = np.abs(d).max(axis=2) > 0.01
+    assert outlier.sum() <= 30, int(outlier.sum())
+    rmse = float(np.sqrt(np.mean(d[~outlier] ** 2)))
+    assert rmse < 2e-4, rmse
+    assert abs(a["rgb"][~outlier].mean() - b["rgb"][~outlier].mean()) < 5e-6
     assert (a["bgr"] != b["bgr"]).mean() < 5e-4
     assert a["stats"]["gi"] == b["stats"]["gi"]
     # bit-reproducible run to run (contribution slots, no float atomics)
     b2 = sc.render(**c, model=model, gi=True, rb=rb, spp=8, gi_precision=device.GI_F32_FAST)
     assert np.array_equal(b["rgb"], b2["rgb"])
+
+
+@pytest.mark.parametrize("name,model,rb,size,n_parts,precision", [
+    ("cbox", 1, False, 512, 2, 1), ("cbox", 0, True, 100, 3, 1), ("car", 1, True, 60, 8, 0), ("pine", 0, False, 512, 8, 1),
+    ("car", 0, False, 9, 4, 1)])
+def test_row_bands_of_all_parts_make_the_whole_view(gpu_scenes, host_scenes, name, model, rb, size, n_parts, precision):
+    """One view split over n_parts workers (PtOptions.part / n_parts; renderParallel's row dealing, mainOMP.cpp:169-174,
+    in bands of 8 rows): each part holds exactly the whole view's values on its own bands and zeros elsewhere, so the
+    parts add up to the whole view bit for bit -- pixels are independent and the RNG is keyed by the pixel.  The ray
+    counts add up too.  Sizes that are not multiples of 8, more parts than bands (size 9: 2 bands, 4 parts)."""
+    c = cam_of(host_scenes(name))
+    sc = gpu_scenes(name)
+    kw = dict(model=model, gi=True, rb=rb, spp=5, size=size, gi_precision=precision, view=2)
+    whole = sc.render(**c, **kw)
+    band = np.arange(size) // 8
+    total = {k: 0 for k in ("primary", "shadow", "mirror", "gi", "omp_retrace")}
+    seen = np.zeros(size, bool)
+    for part in range(n_parts):
+        r = sc.render(**c, part=part, n_parts=n_parts, **kw)
+        own = band % n_parts == part
+        assert not (seen & own).any()
+        seen |= own
+        for k in ("bgr", "rgb"):
+            assert np.array_equal(r[k][own], whole[k][own]), (part, k)
+            assert not r[k][~own].any(), (part, k)
+        for k in ("mesh", "tri", "t", "u", "v"):
+            a, w = r[k].reshape(size, size), whole[k].reshape(size, size)
+            assert np.array_equal(a[own], w[own]), (part, k)
+        assert (r["mesh"].reshape(size, size)[~own] == -1).all() and (r["tri"].reshape(size, size)[~own] == -1).all()
+        for k in ("gclr", "gnrm", "ghit"):
+            assert np.array_equal(r[k].reshape(size, size, 3)[own], whole[k].reshape(size, size, 3)[own]), (part, k)
+        for k in total:
+            total[k] += r["stats"][k]
+    assert seen.all()
+    assert total == {k: whole["stats"][k] for k in total}
+    with pytest.raises(device.DeviceError):
+        sc.render(**c, part=3, n_parts=3, **kw)
 
 
 def test_blob_upload_and_multi_view(gpu_scenes, host_scenes):

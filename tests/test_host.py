@@ -29,7 +29,7 @@ def preorder(nodes, refs):
     return np.array(ni, np.int32), np.array(nd), np.array(ent, np.int64)
 
 
-@pytest.mark.parametrize("name", ["cbox", "car"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
 def test_host_tree_equals_oracle_tree(host_scenes, oracle_scenes, name):
     hs, os_ = host_scenes(name), oracle_scenes(name)
     st, ot = hs.stats, os_.tree_stats()
@@ -43,7 +43,7 @@ def test_host_tree_equals_oracle_tree(host_scenes, oracle_scenes, name):
     assert np.array_equal(tri_mesh[ent], oent[:, 0]) and np.array_equal(tri_local[ent], oent[:, 1])
 
 
-@pytest.mark.parametrize("name", ["cbox", "car"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
 def test_children_adjacent_and_slices_cover_refs(host_scenes, name):
     nodes, refs, _, _ = host_scenes(name).tree_arrays()
     inner = nodes["axis"] >= 0
@@ -77,7 +77,7 @@ def test_bad_inputs_fail_loudly(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="reference scene directory not present")
-@pytest.mark.parametrize("name", ["cbox", "car"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
 def test_text_reader_reproduces_packed_scene(tmp_path, name):
     """The committed packed scenes are what the text reader makes of the reference files."""
     from PIL import Image
@@ -92,7 +92,7 @@ def test_text_reader_reproduces_packed_scene(tmp_path, name):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="reference scene directory not present")
-@pytest.mark.parametrize("name", ["cbox", "car"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
 def test_text_reader_with_own_jpeg_decoder_reproduces_packed_scene(tmp_path, name):
     """Same, with the reader decoding the .jpg textures itself (no decoded .ppm anywhere): the built-in decoder
     yields the texels libjpeg-turbo yields, so the packed file is byte-identical again."""

@@ -39,3 +39,11 @@ def test_round_robin_partition():
             assert sorted(sum(owned, [])) == list(range(n))
             assert all(v % world == r for r, vs in enumerate(owned) for v in vs)
             assert multiview.rounds(n, world) == max((len(o) for o in owned), default=0)
+
+
+def test_row_band_partition():
+    for size in (1, 8, 9, 100, 512):
+        for world in (1, 2, 3, 8):
+            owned = [multiview.bands_of_rank(size, r, world) for r in range(world)]
+            assert sorted(sum(owned, [])) == list(range((size + 7) // 8))
+            assert all(b % world == r for r, bs in enumerate(owned) for b in bs)
