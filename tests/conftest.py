@@ -15,8 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_packed_here = {}
+
+
 def scene_path(name):
-    return os.path.join(SCENES, name + ".ptscene")
+    """Packed scene file of `name`: scenes/<name>.ptscene, or -- for a scene kept as a directory of text files under
+    tests/golden/ -- a temporary file that the host reader packs on first use."""
+    p = os.path.join(SCENES, name + ".ptscene")
+    if os.path.exists(p):
+        return p
+    if name not in _packed_here:
+        import tempfile
+        from pathtracing_amd import host
+        out = os.path.join(tempfile.mkdtemp(prefix="ptscene_"), name + ".ptscene")
+        host.HostScene.from_dir(os.path.join(GOLDEN, name)).save_packed(out)
+        _packed_here[name] = out
+    return _packed_here[name]
 
 
 @pytest.fixture(scope="session")

@@ -32,8 +32,10 @@ def sha(a):
 
 
 def main():
-    for name in ("cbox", "car", "pine"):
-        s = po.OracleScene(os.path.join(ROOT, "scenes", name + ".ptscene"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import scene_path      # scenes/<name>.ptscene, or tests/golden/<name>/ packed by the host reader
+    for name in ("cbox", "car", "pine", "terrace"):
+        s = po.OracleScene(scene_path(name))
         r = s.render(model=po.MODEL_MAIN, threads=8, brute=True)
         deg = (r["mesh"] != r["bmesh"]) | (r["tri"] != r["btri"])
         np.savez_compressed(os.path.join(OUT, f"primary_{name}.npz"), mesh=r["mesh"].astype(np.int8), tri=r["tri"],

@@ -30,11 +30,11 @@ def check_gi(name, tag, r):
     assert np.array_equal(sha(r["bgr"]), g["bgr_sha256"])
 
 
-@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine", "terrace"])
 def test_oracle_reproduces_golden_primary(oracle_scenes, name):
     r = oracle_scenes(name).render(model=po.MODEL_MAIN, threads=8)
     g = check_primary(name, r)
-    assert len(g["degenerate"]) == {"cbox": 0, "car": 29, "pine": 0}[name]
+    assert len(g["degenerate"]) == {"cbox": 0, "car": 29, "pine": 0, "terrace": 0}[name]
 
 
 def test_oracle_reproduces_golden_gi(oracle_scenes):
@@ -43,7 +43,7 @@ def test_oracle_reproduces_golden_gi(oracle_scenes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine", "terrace"])
 def test_gpu_reproduces_golden_primary(gpu_scenes, host_scenes, name):
     """Primary-ray hit ids: identical to the reference search on EVERY pixel, hence also on the
     non-degenerate ones, where they equal the brute-force nearest hit."""
@@ -54,7 +54,7 @@ def test_gpu_reproduces_golden_primary(gpu_scenes, host_scenes, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,model,tag", [("cbox", 0, "main"), ("cbox", 1, "omp"), ("car", 0, "main"), ("car", 1, "omp"),
-                                            ("pine", 0, "main"), ("pine", 1, "omp")])
+                                            ("pine", 0, "main"), ("pine", 1, "omp"), ("terrace", 0, "main"), ("terrace", 1, "omp")])
 def test_gpu_reproduces_golden_gi(gpu_scenes, host_scenes, name, model, tag):
     c = host_scenes(name).camera()
     r = gpu_scenes(name).render(c["eye"], c["angle"], c["zoom"], model=model, gi=True, seed=0x5EED, view=3, gi_precision=0)

@@ -46,13 +46,13 @@ def test_hemisphere_samples_bit_exact(gpu_scenes):
         assert np.array_equal(device.hemisphere_samples(seed, view, pixel, 4096), po.hemisphere_samples(seed, view, pixel, 4096))
 
 
-@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine", "terrace"])
 def test_direct_frame_bit_exact_main(gpu_scenes, oracle_scenes, host_scenes, name):
     """config 1 (cbox direct, main.cpp model) and the same for car: every output bit for bit."""
     c = cam_of(host_scenes(name))
     g = gpu_scenes(name).render(**c, model=device.MODEL_MAIN)
     o = oracle_scenes(name).render(**c, model=po.MODEL_MAIN, threads=16)
-    assert (g["mesh"] >= 0).sum() == 512 * 512
+    assert (g["mesh"] >= 0).sum() == (512 * 512 if name != "terrace" else 177907)    # terrace is open: sky pixels
     assert_same_frame(g, o, name + " direct")
     oc = o["counts"]
     st = g["stats"]
@@ -60,7 +60,7 @@ def test_direct_frame_bit_exact_main(gpu_scenes, oracle_scenes, host_scenes, nam
 
 
 @pytest.mark.parametrize("name,model,rb", [("cbox", 0, False), ("cbox", 0, True), ("cbox", 1, False), ("cbox", 1, True),
-                                           ("car", 0, False), ("car", 1, False), ("pine", 0, True), ("pine", 1, False)])
+                                           ("car", 0, False), ("car", 1, False), ("pine", 0, True), ("pine", 1, False), ("terrace", 0, False), ("terrace", 1, True)])
 def test_gi_frame_bit_exact(gpu_scenes, oracle_scenes, host_scenes, name, model, rb):
     """-gi (and -gi -rb) with the counter RNG: the fp64 path reproduces the oracle image exactly."""
     c = cam_of(host_scenes(name))
@@ -110,7 +110,7 @@ def random_rays(n, seed, box):
     return src, d
 
 
-@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine", "terrace"])
 def test_trace_random_rays_bit_exact(gpu_scenes, oracle_scenes, name):
     """pt_trace mode 0 == search() of the reference on incoherent rays, closest-hit and bounded."""
     s = oracle_scenes(name)
@@ -123,7 +123,7 @@ def test_trace_random_rays_bit_exact(gpu_scenes, oracle_scenes, name):
     assert gpu_scenes(name).trace(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0))["found"].size == 0
 
 
-@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine", "terrace"])
 def test_fast_trace_against_brute_force(gpu_scenes, oracle_scenes, name):
     """pt_trace mode 1 (fp32 kd traversal, the GI fast path) finds the true nearest hit:
     same triangle as an fp64 brute force wherever the two nearest candidates are not
@@ -148,7 +148,7 @@ def check_fast_trace(g, o):
 
 
 @pytest.mark.parametrize("name,model,rb", [("cbox", 0, False), ("cbox", 1, False), ("car", 0, False), ("car", 1, False),
-                                           ("cbox", 0, True), ("car", 1, True), ("pine", 0, False), ("pine", 1, True)])
+                                           ("cbox", 0, True), ("car", 1, True), ("pine", 0, False), ("pine", 1, True), ("terrace", 0, True), ("terrace", 1, False)])
 def test_fast_gi_image_close_to_exact(gpu_scenes, host_scenes, name, model, rb):
     """fp32 GI wavefront path vs fp64 path at equal spp and equal sample directions.  A handful of the 2 M sample
     rays end on another triangle (the reference search is not always a nearest-hit search, and fp32 may pick the

@@ -29,7 +29,7 @@ def preorder(nodes, refs):
     return np.array(ni, np.int32), np.array(nd), np.array(ent, np.int64)
 
 
-@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine", "terrace"])
 def test_host_tree_equals_oracle_tree(host_scenes, oracle_scenes, name):
     hs, os_ = host_scenes(name), oracle_scenes(name)
     st, ot = hs.stats, os_.tree_stats()
@@ -43,7 +43,7 @@ def test_host_tree_equals_oracle_tree(host_scenes, oracle_scenes, name):
     assert np.array_equal(tri_mesh[ent], oent[:, 0]) and np.array_equal(tri_local[ent], oent[:, 1])
 
 
-@pytest.mark.parametrize("name", ["cbox", "car", "pine"])
+@pytest.mark.parametrize("name", ["cbox", "car", "pine", "terrace"])
 def test_children_adjacent_and_slices_cover_refs(host_scenes, name):
     nodes, refs, _, _ = host_scenes(name).tree_arrays()
     inner = nodes["axis"] >= 0
