@@ -11,7 +11,9 @@ With --split-rows every view is rendered by all N GPUs together instead, each th
 """
 import argparse
 import os
+import queue
 import sys
+import threading
 import time
 
 import numpy as np
@@ -79,20 +81,42 @@ def main(argv=None):
         return frame if a.backend == "nccl" else frame.cpu()
 
     t_last = [time.perf_counter()]
+    # Files are written by a second thread, so that the GPU renders the next view meanwhile (the render call and the
+    # file write both release the interpreter lock).
+    pending = queue.Queue(maxsize=8)
+    failed = []
+
+    def writer():
+        while True:
+            item = pending.get()
+            if item is None:
+                return
+            try:
+                host.write_image(os.path.join(a.out, f"{a.scene}{item[0]}.ppm"), item[1].reshape(n, n, 3))
+            except Exception as e:                                                                      # reported after the loop
+                failed.append(e)
 
     def on_frame(v, pixels):
         now = time.perf_counter()
         print(f"Elapsed time: {now - t_last[0]:g} s")                                                   # mainOMP.cpp:241
         t_last[0] = now
-        host.write_image(os.path.join(a.out, f"{a.scene}{v}.ppm"), pixels.reshape(n, n, 3))
+        pending.put((v, pixels))
 
+    wthread = None
     if rank == 0:
         os.makedirs(a.out, exist_ok=True)
+        wthread = threading.Thread(target=writer, daemon=True)
+        wthread.start()
     t0 = time.perf_counter()
     if a.split_rows:
         multiview.run_split_views(render, len(cams), n, xdev, dist if world > 1 else None, on_frame if rank == 0 else None)
     else:
         multiview.run_views(render, len(cams), frame.numel(), xdev, dist if world > 1 else None, on_frame if rank == 0 else None)
+    if wthread is not None:
+        pending.put(None)
+        wthread.join()
+        if failed:
+            sys.exit(f"writing frames failed: {failed[0]}")
     if world > 1:
         dist.barrier()
     if rank == 0:
