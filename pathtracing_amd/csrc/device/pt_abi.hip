@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -23,6 +25,20 @@ thread_local std::string g_error;
 int g_device = -1;
 
 int fail(int code, const std::string &msg) { g_error = msg; return code; }
+
+// Every entry point that may allocate host memory runs inside this: nothing is thrown across the C boundary.
+template <typename F>
+int guarded(F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        try { return fail(PT_ERR_OOM, "out of host memory"); } catch (...) { return PT_ERR_OOM; }
+    } catch (const std::exception &e) {
+        try { return fail(PT_ERR_INVALID, std::string("unexpected exception: ") + e.what()); } catch (...) { return PT_ERR_INVALID; }
+    } catch (...) {
+        return PT_ERR_INVALID;
+    }
+}
 
 float bits_to_float(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
 
@@ -168,9 +184,11 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     if (depth + 1 > PT_STACK_MAX)
         return fail(PT_ERR_LIMIT, "kd-tree depth " + std::to_string(depth) + " exceeds the traversal stack (" +
                                       std::to_string(PT_STACK_MAX) + ")");
-    PtScene *sc = new (std::nothrow) PtScene();
+    struct Free { void operator()(PtScene *p) const { pt_scene_free(p); } };
+    std::unique_ptr<PtScene, Free> holder(new (std::nothrow) PtScene());      // freed on every early return and on a throw
+    PtScene *sc = holder.get();
     if (!sc) return fail(PT_ERR_OOM, "out of host memory");
-    auto bail = [&](int code) { pt_scene_free(sc); return code; };
+    auto bail = [](int code) { return code; };
     sc->max_depth = depth;
     sc->n_tri = d->n_tri; sc->n_mesh = d->n_mesh;
     sc->tri_mesh.assign(d->tri_mesh, d->tri_mesh + d->n_tri);
@@ -313,7 +331,7 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     if (e == hipSuccess) e = hipEventCreate(&sc->ev0);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
     if (e != hipSuccess) return bail(fail(PT_ERR_HIP, std::string("stream/event creation: ") + hipGetErrorString(e)));
-    *out = sc;
+    *out = holder.release();
     return PT_OK;
 }
 
@@ -466,7 +484,7 @@ int pt_init(int device) {
 
 int pt_shutdown(void) { g_device = -1; return PT_OK; }
 
-int pt_scene_upload(const PtSceneDesc *desc, PtScene **out) { return upload(desc, out); }
+int pt_scene_upload(const PtSceneDesc *desc, PtScene **out) { return guarded([&] { return upload(desc, out); }); }
 
 int pt_scene_info(const PtScene *sc, PtSceneInfo *out) {
     if (!sc || !out) return fail(PT_ERR_INVALID, "pt_scene_info: null argument");
@@ -523,7 +541,7 @@ int pt_scene_blob_size(const PtSceneDesc *desc, size_t *bytes) {
     return PT_OK;
 }
 
-int pt_scene_blob_write(const PtSceneDesc *d, void *blob, size_t bytes) {
+int pt_scene_blob_write(const PtSceneDesc *d, void *blob, size_t bytes) { return guarded([&]() -> int {
     int rc = validate_desc(d);
     if (rc) return rc;
     if (!blob || bytes < blob_bytes(d)) return fail(PT_ERR_INVALID, "blob buffer too small");
@@ -551,9 +569,9 @@ int pt_scene_blob_write(const PtSceneDesc *d, void *blob, size_t bytes) {
     put(d->nodes, (size_t)d->n_node * sizeof(PtKdNode));
     put(d->refs, (size_t)d->n_ref * 4);
     return PT_OK;
-}
+}); }
 
-int pt_scene_upload_blob(const void *blob, size_t bytes, PtScene **out) {
+int pt_scene_upload_blob(const void *blob, size_t bytes, PtScene **out) { return guarded([&]() -> int {
     if (!blob || bytes < sizeof(BlobHeader)) return fail(PT_ERR_INVALID, "blob too small");
     const uint8_t *p = (const uint8_t *)blob;
     BlobHeader h;
@@ -592,9 +610,9 @@ int pt_scene_upload_blob(const void *blob, size_t bytes, PtScene **out) {
     d.refs = (const int32_t *)take((size_t)d.n_ref * 4);
     if (!ok) return fail(PT_ERR_INVALID, "scene blob is truncated");
     return upload(&d, out);
-}
+}); }
 
-int pt_render_view(PtScene *sc, const PtCamera *cam, const PtOptions *opt, uint8_t *bgr_out, PtAov *aov, PtStats *stats) {
+int pt_render_view(PtScene *sc, const PtCamera *cam, const PtOptions *opt, uint8_t *bgr_out, PtAov *aov, PtStats *stats) { return guarded([&]() -> int {
     if (!sc) return fail(PT_ERR_INVALID, "scene is null");
     auto t0 = std::chrono::steady_clock::now();
     float gi_ms; uint64_t gi_l;
@@ -621,9 +639,9 @@ int pt_render_view(PtScene *sc, const PtCamera *cam, const PtOptions *opt, uint8
         }
     if (stats) stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PT_OK;
-}
+}); }
 
-int pt_render_view_device(PtScene *sc, const PtCamera *cam, const PtOptions *opt, void *d_bgr, PtStats *stats) {
+int pt_render_view_device(PtScene *sc, const PtCamera *cam, const PtOptions *opt, void *d_bgr, PtStats *stats) { return guarded([&]() -> int {
     if (!sc || !d_bgr) return fail(PT_ERR_INVALID, "scene or output pointer is null");
     auto t0 = std::chrono::steady_clock::now();
     float gi_ms; uint64_t gi_l;
@@ -634,10 +652,10 @@ int pt_render_view_device(PtScene *sc, const PtCamera *cam, const PtOptions *opt
     HIPCHK(hipStreamSynchronize(sc->stream));
     if (stats) stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PT_OK;
-}
+}); }
 
 int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0, uint32_t view_stride,
-                    const PtOptions *opt, uint8_t *frames, PtStats *stats) {
+                    const PtOptions *opt, uint8_t *frames, PtStats *stats) { return guarded([&]() -> int {
     if (!sc || (n && (!cams || !frames))) return fail(PT_ERR_INVALID, "scene, cameras or frames pointer is null");
     int size, N;
     int rc = check_options(opt, &size, &N);
@@ -656,10 +674,10 @@ int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0,
     HIPCHK(hipStreamSynchronize(sc->stream));
     if (stats) stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PT_OK;
-}
+}); }
 
 int pt_trace(PtScene *sc, size_t n, const double *src, const double *dir, const double *tmin_in, int mode,
-             int32_t *found, int32_t *mesh, int32_t *tri, double *t, double *u, double *v) {
+             int32_t *found, int32_t *mesh, int32_t *tri, double *t, double *u, double *v) { return guarded([&]() -> int {
     if (!sc) return fail(PT_ERR_INVALID, "scene is null");
     if (mode != 0 && mode != 1) return fail(PT_ERR_INVALID, "pt_trace: mode must be 0 or 1");
     if (n == 0) return PT_OK;
@@ -700,7 +718,7 @@ int pt_trace(PtScene *sc, size_t n, const double *src, const double *dir, const 
         tri[k] = g < 0 ? -1 : sc->tri_local[g];
     }
     return PT_OK;
-}
+}); }
 
 int pt_camera_rays(const PtCamera *cam, int size, double x, double y, double *dir_out) {
     if (g_device < 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not been called");
