@@ -236,6 +236,22 @@ def test_errors(gpu_scenes, host_scenes):
         sc.render([0, 0, 0], 0.0, 1.0, size=100000)
     with pytest.raises(device.DeviceError):
         device.DeviceScene(blob=np.zeros(64, np.uint8))
+    # a scene blob that was cut short, and one whose tree links or indices were damaged, are refused before
+    # anything reaches the kernels (which index the pools unchecked)
+    blob = device.scene_blob(host_scenes("cbox").desc())
+    with pytest.raises(device.DeviceError):
+        device.DeviceScene(blob=blob[: len(blob) // 2])
+    rng = np.random.default_rng(5)
+    refused = 0
+    for _ in range(8):
+        bad = blob.copy()
+        at = rng.integers(len(bad) // 2, len(bad) - 4, 64)         # the second half holds kd nodes and references
+        bad[at] = 0xFF
+        try:
+            device.DeviceScene(blob=bad).close()
+        except device.DeviceError:
+            refused += 1
+    assert refused >= 6
 
 
 @pytest.fixture(scope="module")
