@@ -164,13 +164,24 @@ def main():
     size = 512
     opt = dict(gi=True, rb=a.rb, model=model, spp=a.spp, gi_precision=device.GI_F32_FAST, size=size)
     frame = torch.empty(size * size * 3, dtype=torch.uint8, device=dev)
-    gather = multiview.FrameGather(frame.numel(), xdev, dist) if world > 1 else None
+    # Finished frames go to rank 0 in one gather per 8 steps (and at the end of the warm-up and of the timed steps):
+    # a gather makes the ranks wait for each other, and views differ in cost.
+    gather = multiview.FrameGather(frame.numel(), xdev, dist, batch=8) if world > 1 else None
 
+    # Weak scaling: step i renders camera i of the path on every rank, each rank with its own RNG key (the view index
+    # i * world + rank of the multi-view job), so that the work per GPU is the same for every N and the N = 1, 2, 4, 8
+    # lines differ by what the extra GPUs cost, not by which cameras happened to fall to them (views differ in cost
+    # by tens of percent).
     def step(i, stats):
-        v = (i * world + rank) % nviews
-        ds.render_to_device(views[v], frame.data_ptr(), stats=stats, view=v, **opt)
+        ds.render_to_device(views[i % nviews], frame.data_ptr(), stats=stats, view=i * world + rank, **opt)
         if world > 1:
-            gather.gather(frame if a.backend == "nccl" else frame.cpu(), i, nviews)       # finished frames go to rank 0
+            gather.slot(i).copy_(frame if a.backend == "nccl" else frame.cpu())
+            if gather.full():
+                gather.flush(1 << 30)
+
+    def flush():
+        if world > 1:
+            gather.flush(1 << 30)
 
     def sync():
         if world > 1:
@@ -180,11 +191,13 @@ def main():
     warm = device.PtStats()
     for i in range(a.warmup):
         step(i, warm)
+    flush()
     stats = device.PtStats()
     sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i, stats)
+    flush()                                  # inside the timed region: the job is done when rank 0 holds every frame
     sync()
     dt = time.perf_counter() - t0
 
@@ -201,10 +214,10 @@ def main():
         # ---- algorithmic bytes per ray of the dominant kernel: a counting run (untimed) ----
         # over exactly the views the timed steps of this rank rendered
         c_gi = c_node = c_tri = 0
-        for i in range(a.steps):
-            v = ((a.warmup + i) * world + rank) % nviews
+        for i in range(a.warmup, a.warmup + a.steps):
             cst = device.PtStats()
-            ds.render_to_device(views[v], frame.data_ptr(), stats=cst, view=v, flags=device.FLAG_COUNT_WORK, **opt)
+            ds.render_to_device(views[i % nviews], frame.data_ptr(), stats=cst, view=i * world + rank,
+                                flags=device.FLAG_COUNT_WORK, **opt)
             c_gi += cst.gi; c_node += cst.gi_nodes_visited; c_tri += cst.gi_tris_tested
         n_node = c_node / max(c_gi, 1)
         n_tri = c_tri / max(c_gi, 1)
@@ -270,7 +283,7 @@ def main():
             "dtype": "f32 (GI sample rays) + f64 (primary, mirror, their shadow rays)",
             "data": "synthetic" if a.workload == "atrium" else ("scene directory supplied by the user" if a.workload == "sponza" else "reference scene file, packed"),
             "config": {"workload": WORKLOADS[a.workload][2], "spp": a.spp, "model": a.model, "rb": bool(a.rb),
-                       "image": "512x512", "views_per_step": world, "parallelism": f"views round-robin over {world} GPU(s)",
+                       "image": "512x512", "views_per_step": world, "parallelism": f"one view per GPU per step on {world} GPU(s): camera = step, RNG key = step * GPUs + rank; frames gathered on rank 0",
                        "triangles": st["triangles"], "kd_refs": st["optimized"], "kd_nodes": st["nodes"],
                        "device_tree": ds.info()},
             "views_per_s": round(a.steps * world / dt_max, 3),

@@ -9,7 +9,9 @@ remain are
 
 * once per job: rank 0 reads the scene, builds the tree and broadcasts the
   packed scene blob (RCCL over xGMI when the tensors live on GPUs);
-* per round of views: the finished BGR8 frames are gathered on rank 0.
+* per batch of rounds: the finished BGR8 frames are gathered on rank 0.  A gather makes the ranks wait for each
+  other, and views differ in cost by tens of percent, so the ranks render several views each (8 by default) between
+  two gathers instead of meeting after every view.
 
 A second mode splits every single view over all ranks (run_split_views): the
 reference's own distribution, rows of one view dealt round-robin to the workers
@@ -64,49 +66,86 @@ def broadcast_cameras(cams, device, dist, src=0):
 
 
 class FrameGather:
-    """Gathers one frame per rank per round on rank 0 and files it under its view index."""
+    """Gathers the frames of up to `batch` rounds per rank on rank 0 in one collective and files them under their view
+    indices.  Each rank puts the frame of round k into slot(k); flush() sends the slots filled since the last flush."""
 
-    def __init__(self, frame_numel, device, dist):
+    def __init__(self, frame_numel, device, dist, batch=1):
         import torch
         self.dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
-        self.recv = ([torch.empty(frame_numel, dtype=torch.uint8, device=device) for _ in range(self.world)]
-                     if self.rank == 0 else None)
+        self.batch, self.numel = max(1, int(batch)), frame_numel
+        self.send = torch.zeros((self.batch, frame_numel), dtype=torch.uint8, device=device)
+        self.recv = ([torch.empty_like(self.send) for _ in range(self.world)] if self.rank == 0 else None)
+        self.first_round, self.filled = 0, 0
+
+    def slot(self, round_index):
+        """The tensor (frame_numel bytes) that takes this rank's frame of round `round_index`; rounds come in order."""
+        if self.filled == 0:
+            self.first_round = round_index
+        assert round_index == self.first_round + self.filled and self.filled < self.batch
+        self.filled += 1
+        return self.send[round_index - self.first_round]
+
+    def full(self):
+        return self.filled == self.batch
+
+    def flush(self, n_views, out=None):
+        """One gather of the filled slots (every rank has filled the same number).  out: on rank 0, optional dict
+        view index -> numpy frame; views at or beyond n_views (the ragged end of the last round) are dropped."""
+        if self.filled == 0:
+            return
+        nb = self.filled
+        if nb == self.batch:
+            self.dist.gather(self.send, self.recv, dst=0)
+        else:
+            self.dist.gather(self.send[:nb].contiguous(), [t[:nb] for t in self.recv] if self.rank == 0 else None, dst=0)
+        if self.rank == 0 and out is not None:
+            for j in range(nb):
+                for r in range(self.world):
+                    v = (self.first_round + j) * self.world + r
+                    if v < n_views:
+                        out[v] = self.recv[r][j].cpu().numpy().copy()
+        self.filled = 0
 
     def gather(self, frame, round_index, n_views, out=None):
-        """frame: this rank's uint8 tensor for view round_index * world + rank (ignored beyond n_views).
-        out: on rank 0, optional dict view index -> numpy frame."""
-        self.dist.gather(frame, self.recv, dst=0)
-        if self.rank == 0 and out is not None:
-            for r in range(self.world):
-                v = round_index * self.world + r
-                if v < n_views:
-                    out[v] = self.recv[r].cpu().numpy().copy()
+        """One frame per rank, gathered at once (a batch of one round)."""
+        self.slot(round_index).copy_(frame)
+        self.flush(n_views, out)
 
 
-def run_views(render, n_views, frame_numel, device, dist, on_frame=None):
+def run_views(render, n_views, frame_numel, device, dist, on_frame=None, batch=8):
     """The -rm job (renderMultiple, mainOMP.cpp:225-247) over all ranks: view v is rendered by rank v % world.
 
-    render(v) -> uint8 tensor of frame_numel bytes on `device` (called only for views this rank owns);
-    on_frame(v, numpy frame) is called on rank 0 for every view, in view order within a round.
-    Works without a process group (world 1).  Returns the number of rounds."""
-    import torch
+    render(v) -> uint8 tensor of frame_numel bytes on `device` (called only for views this rank owns; the tensor may
+    be reused by the next call); on_frame(v, numpy frame) is called on rank 0 for every view, in view order.  The
+    ranks meet once per `batch` rounds.  Works without a process group (world 1).  Returns the number of rounds."""
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
-    gather = FrameGather(frame_numel, device, dist) if world > 1 else None
-    blank = torch.zeros(frame_numel, dtype=torch.uint8, device=device)
+    gather = FrameGather(frame_numel, device, dist, batch) if world > 1 else None
     n_rounds = rounds(n_views, world)
-    for k in range(n_rounds):
-        v = k * world + rank
-        frame = render(v) if v < n_views else blank
-        if world == 1:
-            if on_frame is not None:
-                on_frame(v, frame.cpu().numpy().copy())
-            continue
+
+    def deliver():
         got = {} if rank == 0 else None
-        gather.gather(frame, k, n_views, got)
+        gather.flush(n_views, got)
         if rank == 0 and on_frame is not None:
             for vv in sorted(got):
                 on_frame(vv, got[vv])
+
+    for k in range(n_rounds):
+        v = k * world + rank
+        if world == 1:
+            frame = render(v)
+            if on_frame is not None:
+                on_frame(v, frame.cpu().numpy().copy())
+            continue
+        slot = gather.slot(k)
+        if v < n_views:
+            slot.copy_(render(v))
+        else:
+            slot.zero_()
+        if gather.full():
+            deliver()
+    if world > 1:
+        deliver()
     return n_rounds
 
 
