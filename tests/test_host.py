@@ -221,3 +221,21 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(dl, n), n
     assert b"gfx950" in dl.pt_version()
+
+
+def test_ctypes_mirror_matches_the_c_header(tmp_path):
+    """The ctypes structures of host.py / device.py have the sizes the C compiler gives the structs of the header
+    (the header also compiles as plain C)."""
+    import ctypes
+    import subprocess
+    from pathtracing_amd import device
+    names = ["PtKdNode", "PtTexture", "PtLight", "PtSceneDesc", "PtCamera", "PtOptions", "PtAov", "PtStats", "PtSceneInfo"]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "pathtracing_amd.h"\n#include "pathtracing_host.h"\nint main(void) {\n' +
+                   "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for n in names:
+        cls = getattr(device, n, None) or getattr(host, n)
+        assert ctypes.sizeof(cls) == int(out[n]), n
