@@ -7,9 +7,11 @@ A step is one 512x512 view rendered per GPU (primary + mirror + shadow rays in
 fp64, GI sample rays through the fp32 wavefront path), the frame left in device
 memory and gathered to rank 0.  With N > 1 (one process per GPU, launched by
 torch.distributed.run) rank 0 reads the scene, builds the kd-tree and hands
-the packed scene to the other ranks with one RCCL broadcast; views are dealt
-round-robin, view v -> rank v % N, and no other collective touches the data
-path.  Rank 0 prints one JSON line.
+the packed scene to the other ranks with one RCCL broadcast; step i renders
+camera i of the path on every rank under the RNG key of view i * N + rank of
+the multi-view job (equal work per GPU for every N), the frames go to rank 0
+in one gather per 8 steps, and no other collective touches the data path.
+Rank 0 prints one JSON line.
 
 value    = rays of all classes traced by all ranks / wall time of the K steps
 roofline = the GI closest-hit kernel (the dominant kernel): algorithmic bytes
@@ -36,8 +38,11 @@ WORKLOADS = {
     # the reference ships the sponza textures, master file and camera path but not the mesh (sponza2.txt); when a
     # complete scenes/sponza/ is supplied next to this file it is the default workload, read by the text reader as it is
     "sponza": ("dir:scenes/sponza", "scenes/paths/sponzapath.txt", "sponza -gi, scene directory supplied by the user"),
-    "atrium": (None, None, "atrium-262k -gi: procedural stand-in (262 267 triangles, seed 12345) for the sponza mesh, "
-                           "which is not available; not Crytek Sponza"),
+    "atrium": ("gen:262267", None, "atrium-262k -gi: procedural stand-in (262 267 triangles, seed 12345) for the sponza mesh, "
+                                   "which is not available; not Crytek Sponza"),
+    # the room mesh (bedroom.txt, 340 265 triangles) is not shipped either; its configuration is -gi -rb
+    "room": ("gen:340265", None, "atrium-340k -gi -rb: procedural stand-in (340 265 triangles, seed 12345) at the triangle count of the "
+                                 "room mesh, which is not available; ray bundles on"),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, spec
 
@@ -77,8 +82,8 @@ def default_workload():
 def load_host_scene(name):
     from pathtracing_amd import host
     packed, path_file, _ = WORKLOADS[name]
-    if packed is None:
-        hs = host.HostScene.atrium(262267, 12345)
+    if packed.startswith("gen:"):
+        hs = host.HostScene.atrium(int(packed[4:]), 12345)
     elif packed.startswith("dir:"):
         hs = host.HostScene.from_dir(os.path.join(ROOT, packed[4:]))
     else:
@@ -120,6 +125,8 @@ def main():
                     help="gloo: rehearsal of the N > 1 path with every rank on GPU 0 and the exchanges staged through host memory")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     a = ap.parse_args()
+    if a.workload == "room":
+        a.rb = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -249,7 +256,7 @@ def main():
             from oracle import ptoracle as po
             packed = WORKLOADS[a.workload][0]
             tmp = None
-            if packed is None or packed.startswith("dir:"):
+            if packed.startswith("gen:") or packed.startswith("dir:"):
                 tmp = os.path.join("/tmp", f"bench_{a.workload}_{os.getpid()}.ptscene")
                 hs.save_packed(tmp)
                 packed_path = tmp
