@@ -67,15 +67,39 @@ PT_DEV bool search_node(const DevScene &S, int node, const NodeA &na, const RayD
     return found;
 }
 
+// The nodes whose triangle lists a search has gone through, in order (the first PT_SEQ_MAX of them; n counts all).
+#define PT_SEQ_MAX 192
+struct NodeTrail { int32_t node[PT_SEQ_MAX]; int n; };
+
 // search(), util/kdtree.cpp:216-257.  h.tmin is the in/out bound.
-PT_DEV bool search_ref(const DevScene &S, const RayD &ray, HitD &h) {
+//
+// MODE 0: as written.  MODE 1: also records the trail of nodes whose lists were tested.  MODE 2: a later search
+// of the SAME ray with a bound that is no larger than the one the recording search ended with (mainOMP.cpp:60
+// re-searches the camera ray bounded by its own hit, once per light).  Every triangle of a recorded node was
+// tested then and was either rejected for a reason that does not involve the bound, or had t >= the bound that
+// search ended with (the accepted hit itself: t == bound), so `t < tmin` rejects it again, bit for bit.  The
+// replay therefore walks the tree with its own decisions -- which differ from the first walk where a plane lies
+// beyond the new bound -- and skips the lists for as long as it meets the recorded nodes in the recorded order;
+// from the first node that is not on the trail it tests everything.  Same result as MODE 0, minus the tests.
+template <int MODE>
+PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, NodeTrail *trail) {
     double ent, ext;
+    if (MODE == 1) trail->n = 0;
     if (!box_intersect(S.root_lo, S.root_hi, ray, ent, ext)) return false;
     int32_t sn[PT_STACK_MAX];
     double se[PT_STACK_MAX], sx[PT_STACK_MAX];
     int sp = 0;
     sn[0] = 0; se[0] = ent; sx[0] = ext; sp = 1;
     bool found = false;
+    int at = 0;                       // MODE 2: position on the trail, -1 once the walk has left it
+    const int recorded = MODE == 2 ? (trail->n < PT_SEQ_MAX ? trail->n : PT_SEQ_MAX) : 0;
+    auto tested_before = [&](int node) -> bool {
+        if (MODE == 1) { if (trail->n < PT_SEQ_MAX) trail->node[trail->n] = node; trail->n++; }
+        if (MODE != 2) return false;
+        if (at >= 0 && at < recorded && trail->node[at] == node) { at++; return true; }
+        at = -1;
+        return false;
+    };
     while (sp > 0) {
         sp--;
         int curr = sn[sp];
@@ -83,7 +107,7 @@ PT_DEV bool search_ref(const DevScene &S, const RayD &ray, HitD &h) {
         if (ent >= h.tmin) break;
         NodeA na = S.nodeA[curr];
         while (na.axis >= 0) {
-            if (na.count > 0) found |= search_node(S, curr, na, ray, h);
+            if (na.count > 0 && !tested_before(curr)) found |= search_node(S, curr, na, ray, h);
             double s = na.split;
             int a = na.axis;
             double da = dget(ray.dir, a), sa = dget(ray.src, a);
@@ -102,10 +126,11 @@ PT_DEV bool search_ref(const DevScene &S, const RayD &ray, HitD &h) {
             }
             na = S.nodeA[curr];
         }
-        if (na.count > 0 && search_node(S, curr, na, ray, h)) return true;
+        if (na.count > 0 && !tested_before(curr) && search_node(S, curr, na, ray, h)) return true;
     }
     return found;
 }
+PT_DEV bool search_ref(const DevScene &S, const RayD &ray, HitD &h) { return search_ref_t<0>(S, ray, h, nullptr); }
 
 // ---- shading ------------------------------------------------------------------
 
@@ -193,7 +218,8 @@ struct PrimRec { int32_t found, tri; double t, u, v; };
 template <int MODEL, bool PRIMARY>
 PT_DEV D3 cast_ray(const DevScene &S, const RayD &ray, int depth, GBufD *g, PrimRec *rec, RayCounts &rc) {
     HitD h; h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
-    bool ok = search_ref(S, ray, h);
+    NodeTrail trail;
+    bool ok = MODEL == PT_MODEL_OMP ? search_ref_t<1>(S, ray, h, &trail) : search_ref(S, ray, h);
     if (rec) { rec->found = ok; rec->tri = h.tri; rec->t = h.tmin; rec->u = h.u; rec->v = h.v; }
     if (!ok) {
         if (depth == 0) {
@@ -206,6 +232,7 @@ PT_DEV D3 cast_ray(const DevScene &S, const RayD &ray, int depth, GBufD *g, Prim
     surface_properties(S, h.tri, h.u, h.v, nrm, txt, reft);
     D3 hit = dadd(dadd(ray.src, dscale(h.tmin, ray.dir)), dscale(0.0001, nrm));
     D3 direct = d3(0, 0, 0), ref = d3(0, 0, 0);
+    bool retrace_clear = false;       // the last re-search found nothing, so it left h as it was and the next one is the same search
     for (int k = 0; k < S.n_light; k++) {
         D3 ldir, shade; double dis;
         illuminate(S.lights[k], hit, ldir, shade, dis);
@@ -216,7 +243,8 @@ PT_DEV D3 cast_ray(const DevScene &S, const RayD &ray, int depth, GBufD *g, Prim
             vis = !search_ref(S, lray, sh);
             rc.n[RC_SHADOW]++;
         } else {                                             // mainOMP.cpp:60: re-traces `ray` bounded by its own hit
-            vis = !search_ref(S, ray, h);
+            if (!retrace_clear) retrace_clear = !search_ref_t<2>(S, ray, h, &trail);
+            vis = retrace_clear;
             rc.n[RC_RETRACE]++;
         }
         double cosv = ddot(ldir, nrm);
