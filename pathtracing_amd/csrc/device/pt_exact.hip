@@ -169,14 +169,26 @@ __global__ void k_resolve(FrameBuffers F, int size, int gi, int nsamples) {
     F.bgr[3 * p + 2] = (uint8_t)(r < 255 ? r : 255);
 }
 
-// search() on caller-supplied rays.
+// search() on caller-supplied rays.  With `research` the outputs are those of a second search of the same ray bounded
+// by the first one's hit (mainOMP.cpp:60), done the way cast_ray does it: replayed along the first search's node trail.
 __global__ void k_trace_exact(DevScene S, size_t n, const double *src, const double *dir, const double *tmin_in,
-                              int32_t *found, int32_t *tri, double *t, double *u, double *v) {
+                              int32_t *found, int32_t *tri, double *t, double *u, double *v, int research) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     RayD ray = make_ray(dload(src + 3 * k), dload(dir + 3 * k));
     HitD h; h.tmin = tmin_in[k]; h.tri = -1; h.u = 0; h.v = 0;
-    bool ok = search_ref(S, ray, h);
+    bool ok;
+    if (research) {
+        NodeTrail trail;
+        ok = search_ref_t<1>(S, ray, h, &trail);
+        if (ok) {
+            h.tri = -1; h.u = 0; h.v = 0;                 // the bound stays: the first hit's distance
+            if (research == 2) trail.n /= 2;              // test aid: the replay has to leave the trail half-way
+            ok = search_ref_t<2>(S, ray, h, &trail);
+        }
+    } else {
+        ok = search_ref(S, ray, h);
+    }
     found[k] = ok; tri[k] = h.tri; t[k] = h.tmin; u[k] = h.u; v[k] = h.v;
 }
 
@@ -236,8 +248,8 @@ int resolve_frame(const FrameBuffers &F, int size, int gi, int nsamples, hipStre
 }
 
 int exact_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
-                int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s) {
-    hipLaunchKernelGGL(k_trace_exact, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, S, n, src, dir, tmin_in, found, tri, t, u, v);
+                int32_t *found, int32_t *tri, double *t, double *u, double *v, int research, hipStream_t s) {
+    hipLaunchKernelGGL(k_trace_exact, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, S, n, src, dir, tmin_in, found, tri, t, u, v, research);
     return LAUNCH_OK();
 }
 

@@ -73,7 +73,7 @@ int exact_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, int 
 int gi_accumulate(const FrameBuffers &F, int size, int nb, int first_batch, hipStream_t s);
 int resolve_frame(const FrameBuffers &F, int size, int gi, int nsamples, hipStream_t s);
 int exact_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
-                int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s);
+                int32_t *found, int32_t *tri, double *t, double *u, double *v, int research, hipStream_t s);
 int camera_rays(const ViewParams &V, double x, double y, double *dir, hipStream_t s);
 int hemisphere_samples(uint32_t seed, uint32_t view, uint32_t pixel, int n, double *out, hipStream_t s);
 
