@@ -177,9 +177,7 @@ int pt_render_views(PtScene *scene, const PtCamera *cams, size_t n, uint32_t vie
    followed, for a ray that hit, by the second search of the same ray bounded
    by that hit which mainOMP.cpp:60 makes per light -- the outputs are the
    second search's (found = it found something closer; t = the first hit's
-   distance when it did not, with mesh = tri = -1); mode 3: mode 2 with the
-   record the second search replays cut in half, so that it has to fall
-   back to testing triangles half-way (a test aid; same outputs). */
+   distance when it did not, with mesh = tri = -1). */
 int pt_trace(PtScene *scene, size_t n, const double *src, const double *dir, const double *tmin_in, int mode,
              int32_t *found, int32_t *mesh, int32_t *tri, double *t, double *u, double *v);
 

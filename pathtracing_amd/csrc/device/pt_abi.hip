@@ -679,7 +679,7 @@ int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0,
 int pt_trace(PtScene *sc, size_t n, const double *src, const double *dir, const double *tmin_in, int mode,
              int32_t *found, int32_t *mesh, int32_t *tri, double *t, double *u, double *v) { return guarded([&]() -> int {
     if (!sc) return fail(PT_ERR_INVALID, "scene is null");
-    if (mode < 0 || mode > 3) return fail(PT_ERR_INVALID, "pt_trace: mode must be 0 .. 3");
+    if (mode < 0 || mode > 2) return fail(PT_ERR_INVALID, "pt_trace: mode must be 0, 1 or 2");
     if (n == 0) return PT_OK;
     if (!src || !dir || !tmin_in || !found || !mesh || !tri || !t || !u || !v) return fail(PT_ERR_INVALID, "pt_trace: null array");
     if (n > ((size_t)1 << 28)) return fail(PT_ERR_LIMIT, "pt_trace: more than 2^28 rays in one call");
@@ -701,7 +701,7 @@ int pt_trace(PtScene *sc, size_t n, const double *src, const double *dir, const 
     TR(hipMemcpyAsync(d_dir, dir, n * 24, hipMemcpyHostToDevice, s));
     TR(hipMemcpyAsync(d_tmin, tmin_in, n * 8, hipMemcpyHostToDevice, s));
     if (mode == 1 ? fast_trace(sc->S, n, d_src, d_dir, d_tmin, d_found, d_tri, d_t, d_u, d_v, s)
-                  : exact_trace(sc->S, n, d_src, d_dir, d_tmin, d_found, d_tri, d_t, d_u, d_v, mode == 0 ? 0 : mode - 1, s)) {
+                  : exact_trace(sc->S, n, d_src, d_dir, d_tmin, d_found, d_tri, d_t, d_u, d_v, mode == 2, s)) {
         cleanup();
         return fail(PT_ERR_HIP, std::string("pt_trace launch: ") + hipGetErrorString(hipGetLastError()));
     }

@@ -67,39 +67,34 @@ PT_DEV bool search_node(const DevScene &S, int node, const NodeA &na, const RayD
     return found;
 }
 
-// The nodes whose triangle lists a search has gone through, in order (the first PT_SEQ_MAX of them; n counts all).
-#define PT_SEQ_MAX 192
-struct NodeTrail { int32_t node[PT_SEQ_MAX]; int n; };
+// What a search notes for the sake of a later search of the SAME ray bounded by the hit it returned
+// (mainOMP.cpp:60 searches the camera ray again, once per light):
+//   far_max   the largest tmid among the steps that took the far child only (util/kdtree.cpp:242-243)
+//   stack_min the smallest entry distance left on the stack when the search ended
+// The later search makes the decisions of this one again under a bound that is no larger.  A smaller bound can only
+// (a) leave far children unpushed, (b) stop at a popped entry sooner -- both make it visit fewer of the same nodes --
+// (c) turn a far-only step into a near step, if that step's tmid lies beyond the bound, or (d) go on to a stack entry
+// that this search never reached because it returned first, if that entry starts before the bound.  While it stays on
+// this search's nodes every triangle it meets was tested here and either failed for a reason that does not involve
+// the bound or had t >= the bound this search ended with (the returned hit itself: t == bound), so `t < tmin` fails
+// again, bit for bit.  Hence: unless far_max > t_hit (c) or stack_min < t_hit (d), the later search finds nothing and
+// leaves the hit record alone, and need not be run.  tests/research_check.c checks this rule on the CPU.
+struct SearchNote {
+    double far_max, stack_min;
+    PT_DEV bool may_find_closer(double t_hit) const { return far_max > t_hit || stack_min < t_hit; }
+};
 
-// search(), util/kdtree.cpp:216-257.  h.tmin is the in/out bound.
-//
-// MODE 0: as written.  MODE 1: also records the trail of nodes whose lists were tested.  MODE 2: a later search
-// of the SAME ray with a bound that is no larger than the one the recording search ended with (mainOMP.cpp:60
-// re-searches the camera ray bounded by its own hit, once per light).  Every triangle of a recorded node was
-// tested then and was either rejected for a reason that does not involve the bound, or had t >= the bound that
-// search ended with (the accepted hit itself: t == bound), so `t < tmin` rejects it again, bit for bit.  The
-// replay therefore walks the tree with its own decisions -- which differ from the first walk where a plane lies
-// beyond the new bound -- and skips the lists for as long as it meets the recorded nodes in the recorded order;
-// from the first node that is not on the trail it tests everything.  Same result as MODE 0, minus the tests.
-template <int MODE>
-PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, NodeTrail *trail) {
+// search(), util/kdtree.cpp:216-257.  h.tmin is the in/out bound.  NOTED: also fills *note.
+template <bool NOTED>
+PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, SearchNote *note) {
     double ent, ext;
-    if (MODE == 1) trail->n = 0;
+    if (NOTED) { note->far_max = -DBL_MAX; note->stack_min = DBL_MAX; }
     if (!box_intersect(S.root_lo, S.root_hi, ray, ent, ext)) return false;
     int32_t sn[PT_STACK_MAX];
     double se[PT_STACK_MAX], sx[PT_STACK_MAX];
     int sp = 0;
     sn[0] = 0; se[0] = ent; sx[0] = ext; sp = 1;
-    bool found = false;
-    int at = 0;                       // MODE 2: position on the trail, -1 once the walk has left it
-    const int recorded = MODE == 2 ? (trail->n < PT_SEQ_MAX ? trail->n : PT_SEQ_MAX) : 0;
-    auto tested_before = [&](int node) -> bool {
-        if (MODE == 1) { if (trail->n < PT_SEQ_MAX) trail->node[trail->n] = node; trail->n++; }
-        if (MODE != 2) return false;
-        if (at >= 0 && at < recorded && trail->node[at] == node) { at++; return true; }
-        at = -1;
-        return false;
-    };
+    bool found = false, at_leaf = false;
     while (sp > 0) {
         sp--;
         int curr = sn[sp];
@@ -107,7 +102,7 @@ PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, NodeTrail 
         if (ent >= h.tmin) break;
         NodeA na = S.nodeA[curr];
         while (na.axis >= 0) {
-            if (na.count > 0 && !tested_before(curr)) found |= search_node(S, curr, na, ray, h);
+            if (na.count > 0) found |= search_node(S, curr, na, ray, h);
             double s = na.split;
             int a = na.axis;
             double da = dget(ray.dir, a), sa = dget(ray.src, a);
@@ -117,20 +112,24 @@ PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, NodeTrail 
             if (sa > s) { int x = nr; nr = fr; fr = x; }
             if (tmid >= ext || tmid < 0)
                 curr = nr;
-            else if (tmid <= ent && tmid <= h.tmin)
+            else if (tmid <= ent && tmid <= h.tmin) {
+                if (NOTED && tmid > note->far_max) note->far_max = tmid;
                 curr = fr;
-            else {
+            } else {
                 if (tmid <= h.tmin && sp < PT_STACK_MAX) { sn[sp] = fr; se[sp] = tmid; sx[sp] = ext; sp++; }
                 curr = nr;
                 ext = tmid;
             }
             na = S.nodeA[curr];
         }
-        if (na.count > 0 && !tested_before(curr) && search_node(S, curr, na, ray, h)) return true;
+        if (na.count > 0 && search_node(S, curr, na, ray, h)) { at_leaf = true; break; }
     }
-    return found;
+    if (NOTED)
+        for (int i = 0; i < sp; i++)
+            if (se[i] < note->stack_min) note->stack_min = se[i];
+    return at_leaf || found;
 }
-PT_DEV bool search_ref(const DevScene &S, const RayD &ray, HitD &h) { return search_ref_t<0>(S, ray, h, nullptr); }
+PT_DEV bool search_ref(const DevScene &S, const RayD &ray, HitD &h) { return search_ref_t<false>(S, ray, h, nullptr); }
 
 // ---- shading ------------------------------------------------------------------
 
@@ -218,8 +217,8 @@ struct PrimRec { int32_t found, tri; double t, u, v; };
 template <int MODEL, bool PRIMARY>
 PT_DEV D3 cast_ray(const DevScene &S, const RayD &ray, int depth, GBufD *g, PrimRec *rec, RayCounts &rc) {
     HitD h; h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
-    NodeTrail trail;
-    bool ok = MODEL == PT_MODEL_OMP ? search_ref_t<1>(S, ray, h, &trail) : search_ref(S, ray, h);
+    SearchNote note;
+    bool ok = MODEL == PT_MODEL_OMP ? search_ref_t<true>(S, ray, h, &note) : search_ref(S, ray, h);
     if (rec) { rec->found = ok; rec->tri = h.tri; rec->t = h.tmin; rec->u = h.u; rec->v = h.v; }
     if (!ok) {
         if (depth == 0) {
@@ -232,7 +231,9 @@ PT_DEV D3 cast_ray(const DevScene &S, const RayD &ray, int depth, GBufD *g, Prim
     surface_properties(S, h.tri, h.u, h.v, nrm, txt, reft);
     D3 hit = dadd(dadd(ray.src, dscale(h.tmin, ray.dir)), dscale(0.0001, nrm));
     D3 direct = d3(0, 0, 0), ref = d3(0, 0, 0);
-    bool retrace_clear = false;       // the last re-search found nothing, so it left h as it was and the next one is the same search
+    // mainOMP.cpp:60: known to find nothing -- by the note of the first search, or because the last one found nothing
+    // and so left h as it was, which makes the next one the same search
+    bool retrace_clear = MODEL == PT_MODEL_OMP && !note.may_find_closer(h.tmin);
     for (int k = 0; k < S.n_light; k++) {
         D3 ldir, shade; double dis;
         illuminate(S.lights[k], hit, ldir, shade, dis);
@@ -243,7 +244,7 @@ PT_DEV D3 cast_ray(const DevScene &S, const RayD &ray, int depth, GBufD *g, Prim
             vis = !search_ref(S, lray, sh);
             rc.n[RC_SHADOW]++;
         } else {                                             // mainOMP.cpp:60: re-traces `ray` bounded by its own hit
-            if (!retrace_clear) retrace_clear = !search_ref_t<2>(S, ray, h, &trail);
+            if (!retrace_clear) retrace_clear = !search_ref(S, ray, h);
             vis = retrace_clear;
             rc.n[RC_RETRACE]++;
         }

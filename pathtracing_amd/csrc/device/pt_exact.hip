@@ -170,7 +170,7 @@ __global__ void k_resolve(FrameBuffers F, int size, int gi, int nsamples) {
 }
 
 // search() on caller-supplied rays.  With `research` the outputs are those of a second search of the same ray bounded
-// by the first one's hit (mainOMP.cpp:60), done the way cast_ray does it: replayed along the first search's node trail.
+// by the first one's hit (mainOMP.cpp:60), done the way cast_ray does it: only when the first search's note asks for it.
 __global__ void k_trace_exact(DevScene S, size_t n, const double *src, const double *dir, const double *tmin_in,
                               int32_t *found, int32_t *tri, double *t, double *u, double *v, int research) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -179,12 +179,11 @@ __global__ void k_trace_exact(DevScene S, size_t n, const double *src, const dou
     HitD h; h.tmin = tmin_in[k]; h.tri = -1; h.u = 0; h.v = 0;
     bool ok;
     if (research) {
-        NodeTrail trail;
-        ok = search_ref_t<1>(S, ray, h, &trail);
+        SearchNote note;
+        ok = search_ref_t<true>(S, ray, h, &note);
         if (ok) {
             h.tri = -1; h.u = 0; h.v = 0;                 // the bound stays: the first hit's distance
-            if (research == 2) trail.n /= 2;              // test aid: the replay has to leave the trail half-way
-            ok = search_ref_t<2>(S, ray, h, &trail);
+            ok = note.may_find_closer(h.tmin) && search_ref(S, ray, h);
         }
     } else {
         ok = search_ref(S, ray, h);

@@ -124,23 +124,20 @@ def test_trace_random_rays_bit_exact(gpu_scenes, oracle_scenes, name):
 
 
 @pytest.mark.parametrize("name", ["cbox", "car", "pine", "terrace"])
-def test_research_replay_equals_a_second_search(gpu_scenes, oracle_scenes, name):
-    """mainOMP.cpp:60 searches the camera ray a second time, bounded by its own hit.  The device replays that search
-    along the node trail of the first one and tests triangles only off the trail (pt_trace mode 2); the oracle simply
-    searches twice.  Same answers bit for bit on incoherent rays, including the rays whose second search does find
-    something closer, should there be any (none among these rays: the second search only matters on rays where the
-    reference's search is not a nearest-hit search)."""
+def test_second_search_rule_equals_a_second_search(gpu_scenes, oracle_scenes, name):
+    """mainOMP.cpp:60 searches the camera ray a second time, bounded by its own hit.  The device runs that search only
+    when two numbers noted by the first one say it could find something (pt_trace mode 2; the rule itself is checked
+    on the CPU by tests/test_research_rule.py); the oracle simply searches twice.  Same answers bit for bit on
+    incoherent rays."""
     s = oracle_scenes(name)
     src, d = random_rays(40000, 23, s.root_box())
     first = s.trace(src, d, np.full(len(src), device.FLT_MAX), mode=0)
     hit = first["found"] == 1
     second = s.trace(src[hit], d[hit], first["t"][hit], mode=0)
-    # mode 3 cuts the recorded trail in half: the replay then leaves it half-way and tests triangles for the rest
-    for mode in (2, 3):
-        g = gpu_scenes(name).trace(src, d, np.full(len(src), device.FLT_MAX), mode=mode)
-        assert np.array_equal(g["found"][~hit], np.zeros((~hit).sum(), np.int32))
-        for k in ("found", "mesh", "tri", "t", "u", "v"):
-            assert np.array_equal(g[k][hit], second[k]), (mode, k)
+    g = gpu_scenes(name).trace(src, d, np.full(len(src), device.FLT_MAX), mode=2)
+    assert np.array_equal(g["found"][~hit], np.zeros((~hit).sum(), np.int32))
+    for k in ("found", "mesh", "tri", "t", "u", "v"):
+        assert np.array_equal(g[k][hit], second[k]), k
 
 
 @pytest.mark.parametrize("name", ["cbox", "car", "pine", "terrace"])

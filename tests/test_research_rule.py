@@ -1,0 +1,67 @@
+"""The rule by which the device skips the second search of mainOMP.cpp:60, checked on the CPU against the oracle's
+search over a few million rays of every kind the render path shoots (tests/research_check.c states the rule)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, scene_path
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    so = tmp_path_factory.mktemp("research") / "research_check.so"
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-o", str(so),
+                    os.path.join(ROOT, "tests", "research_check.c"), "-lm"], check=True)
+    L = C.CDLL(str(so))
+    L.orc_scene_load.restype = C.c_void_p
+    L.orc_scene_load.argtypes = [C.c_char_p]
+    L.orc_build_tree.argtypes = [C.c_void_p]
+    L.orc_root_box.argtypes = [C.c_void_p, C.c_void_p]
+    L.research_check.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
+
+
+def rays_of_every_kind(box, n, seed):
+    """Origins inside the scene's box (some exactly on its faces and on round coordinates, where split planes lie);
+    directions: uniform, axis-parallel (a zero component takes the reference's 1e-7 substitute), nearly axis-parallel,
+    and fans from one point (camera-like)."""
+    rng = np.random.default_rng(seed)
+    lo, hi = box[:3], box[3:]
+    src = lo + (hi - lo) * rng.random((n, 3))
+    k = n // 8
+    src[:k] = np.round(src[:k])                                      # on integer coordinates
+    face = rng.integers(0, 3, k)
+    src[k:2 * k][np.arange(k), face] = np.where(rng.random(k) < 0.5, lo[face], hi[face])
+    d = rng.normal(size=(n, 3))
+    d[2 * k:3 * k, 0] = 0.0
+    d[3 * k:4 * k, 1:] = 0.0
+    d[4 * k:5 * k, 2] *= 1e-9
+    src[5 * k:6 * k] = src[5 * k]                                    # a fan from one point
+    d[np.abs(d).sum(axis=1) == 0] = (1.0, 0.0, 0.0)
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    return np.ascontiguousarray(src), np.ascontiguousarray(d)
+
+
+@pytest.mark.parametrize("name,n", [("cbox", 400000), ("car", 300000), ("pine", 400000), ("terrace", 400000), ("atrium", 300000)])
+def test_skipping_rule_never_skips_a_search_that_finds_something(checker, tmp_path, name, n):
+    path = scene_path(name) if name != "atrium" else str(tmp_path / "atrium.ptscene")
+    if name == "atrium":                     # the procedural hall at 20 000 triangles: a deep tree with thin cells
+        from pathtracing_amd import host
+        host.HostScene.atrium(20000, 12345).save_packed(path)
+    h = checker.orc_scene_load(os.fsencode(path))
+    assert h
+    checker.orc_build_tree(h)
+    box = np.zeros(6)
+    checker.orc_root_box(h, box.ctypes.data)
+    src, d = rays_of_every_kind(box, n, 77)
+    out = np.zeros(5, np.int64)
+    checker.research_check(h, n, src.ctypes.data, d.ctypes.data, out.ctypes.data)
+    hits, again, found2, restatement_differs, wrong_skips = out.tolist()
+    print(name, dict(hits=hits, searched_again=again, second_found=found2))
+    assert hits > n // 4
+    assert restatement_differs == 0          # the noted search of the helper is the oracle's search
+    assert wrong_skips == 0                  # the rule itself
+    assert again < hits // 20                # and it pays: it asks for the second search on few rays
