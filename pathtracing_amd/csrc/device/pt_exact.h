@@ -13,11 +13,22 @@ struct HitD { int32_t tri; double tmin, u, v; };
 
 struct RayCounts { uint32_t n[RC_N]; };
 
+// Loads through the scalar unit, for addresses that are the same in every active lane of the wave (constant
+// address space: the scene is read-only for the kernels).  The rays of a wave are neighbours -- the nine sub-rays
+// of a bundle, the pixels of a tile -- and are in the same node testing the same triangle most of the time; the fp64
+// search is bound by per-lane load requests (72 bytes of triangle = 5 requests per lane and test), and a scalar load
+// is one request per wave.
+typedef const double __attribute__((address_space(4))) *PtUniformD;
+typedef const int32_t __attribute__((address_space(4))) *PtUniformI;
+PT_DEV D3 uload3(const double *p) {
+    PtUniformD q = (PtUniformD)(uintptr_t)p;
+    return d3(q[0], q[1], q[2]);
+}
+
 // Moeller-Trumbore as util/polygonMesh.cpp:54-74 (two-sided, three divides).
 // v0, e1 = v1 - v0, e2 = v2 - v0 are precomputed in fp64 on the host with the
 // same subtractions the reference performs per call.
-PT_DEV bool tri_intersect(const double *__restrict__ T9, const RayD &ray, double &t, double &bu, double &bv) {
-    D3 v0 = dload(T9), ba = dload(T9 + 3), ca = dload(T9 + 6);
+PT_DEV bool tri_intersect(const D3 &v0, const D3 &ba, const D3 &ca, const RayD &ray, double &t, double &bu, double &bv) {
     D3 P = dcross(ray.dir, ca);
     double det = ddot(P, ba);
     D3 T = dsub(ray.src, v0);
@@ -51,10 +62,30 @@ PT_DEV bool box_intersect(const double lo[3], const double hi[3], const RayD &r,
 // point lies inside the node's own box (inclusive on all three axes).
 PT_DEV bool search_node(const DevScene &S, int node, const NodeA &na, const RayD &ray, HitD &h) {
     bool found = false;
+    const int node0 = __builtin_amdgcn_readfirstlane(node);
+    if (__all(node == node0)) {
+        // every active lane is in this node: its list comes through the scalar unit, once for the wave
+        const int first0 = __builtin_amdgcn_readfirstlane(na.first), count0 = __builtin_amdgcn_readfirstlane(na.count);
+        const double *tri = S.refTri + (size_t)first0 * 9;
+        for (int i = 0; i < count0; i++, tri += 9) {
+            double t, bu, bv;
+            if (tri_intersect(uload3(tri), uload3(tri + 3), uload3(tri + 6), ray, t, bu, bv) && t > 0 && t < h.tmin) {
+                D3 hit = dadd(ray.src, dscale(t, ray.dir));
+                const double *b = S.nodeBox + (size_t)node0 * 6;
+                const D3 lo = uload3(b), hi = uload3(b + 3);
+                if (!(hit.x >= lo.x && hit.y >= lo.y && hit.z >= lo.z && hit.x <= hi.x && hit.y <= hi.y && hit.z <= hi.z))
+                    continue;
+                found = true;
+                h.tmin = t; h.u = bu; h.v = bv;
+                h.tri = ((PtUniformI)(uintptr_t)S.refId)[first0 + i];
+            }
+        }
+        return found;
+    }
     const double *tri = S.refTri + (size_t)na.first * 9;
     for (int i = 0; i < na.count; i++, tri += 9) {
         double t, bu, bv;
-        if (tri_intersect(tri, ray, t, bu, bv) && t > 0 && t < h.tmin) {
+        if (tri_intersect(dload(tri), dload(tri + 3), dload(tri + 6), ray, t, bu, bv) && t > 0 && t < h.tmin) {
             D3 hit = dadd(ray.src, dscale(t, ray.dir));
             const double *b = S.nodeBox + (size_t)node * 6;
             if (!(hit.x >= b[0] && hit.y >= b[1] && hit.z >= b[2] && hit.x <= b[3] && hit.y <= b[4] && hit.z <= b[5]))
@@ -65,6 +96,19 @@ PT_DEV bool search_node(const DevScene &S, int node, const NodeA &na, const RayD
         }
     }
     return found;
+}
+
+// A node of the fp64 tree; through the scalar unit when every active lane wants the same one.
+PT_DEV NodeA fetch_node(const DevScene &S, int curr) {
+    const int curr0 = __builtin_amdgcn_readfirstlane(curr);
+    if (__all(curr == curr0)) {
+        typedef const NodeA __attribute__((address_space(4))) *PtUniformNode;
+        PtUniformNode q = (PtUniformNode)(uintptr_t)S.nodeA + curr0;
+        NodeA n;
+        n.split = q->split; n.axis = q->axis; n.left = q->left; n.first = q->first; n.count = q->count;
+        return n;
+    }
+    return S.nodeA[curr];
 }
 
 // What a search notes for the sake of a later search of the SAME ray bounded by the hit it returned
@@ -100,7 +144,7 @@ PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, SearchNote
         int curr = sn[sp];
         ent = se[sp]; ext = sx[sp];
         if (ent >= h.tmin) break;
-        NodeA na = S.nodeA[curr];
+        NodeA na = fetch_node(S, curr);
         while (na.axis >= 0) {
             if (na.count > 0) found |= search_node(S, curr, na, ray, h);
             double s = na.split;
@@ -120,7 +164,7 @@ PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, SearchNote
                 curr = nr;
                 ext = tmid;
             }
-            na = S.nodeA[curr];
+            na = fetch_node(S, curr);
         }
         if (na.count > 0 && search_node(S, curr, na, ray, h)) { at_leaf = true; break; }
     }
