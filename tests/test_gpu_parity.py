@@ -99,6 +99,31 @@ def test_many_samples_in_batches(gpu_scenes, oracle_scenes):
     assert_same_frame(g, o, "cbox 37 spp")
 
 
+def test_random_option_sweep_bit_exact(gpu_scenes, oracle_scenes, host_scenes):
+    """160 seeded random combinations of scene, shading model, -gi, -rb, sample count, image size, RNG key and a
+    camera moved and turned away from the scene's own: the fp64 path equals the oracle in every output, and so do
+    the ray counts."""
+    rng = np.random.default_rng(2024)
+    names = ["cbox", "car", "pine", "terrace"]
+    for case in range(160):
+        name = names[case % 4]
+        c = cam_of(host_scenes(name))
+        box = oracle_scenes(name).root_box()
+        span = float(np.max(box[3:] - box[:3]))
+        eye = (np.array(c["eye"]) + rng.normal(size=3) * 0.08 * span).tolist()
+        cam = dict(eye=eye, angle=float(c["angle"] + rng.normal() * 0.8), zoom=float(c["zoom"] * rng.uniform(0.6, 1.6)))
+        kw = dict(model=int(rng.integers(0, 2)), gi=bool(rng.integers(0, 2)), rb=bool(rng.integers(0, 2)),
+                  spp=int(rng.integers(1, 8)), size=int(rng.integers(3, 41)), view=int(rng.integers(0, 1000)),
+                  seed=int(rng.integers(0, 2 ** 32)))
+        g = gpu_scenes(name).render(**cam, gi_precision=device.GI_F64_EXACT, **kw)
+        o = oracle_scenes(name).render(**cam, rng=po.RNG_PHILOX, threads=16, **kw)
+        what = f"case {case}: {name} {cam} {kw}"
+        assert_same_frame(g, o, what)
+        oc, st = o["counts"], g["stats"]
+        for k in ("primary", "shadow", "mirror", "gi", "omp_retrace"):
+            assert st[k] == oc[k]["searches"], (what, k)
+
+
 def random_rays(n, seed, box):
     rng = np.random.default_rng(seed)
     lo, hi = np.array(box[:3]), np.array(box[3:])
