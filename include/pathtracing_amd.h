@@ -114,7 +114,9 @@ typedef struct PtAov {
 } PtAov;
 
 /* Ray counters of one or more views; closest-hit and any-hit queries that the
-   image needs.  The re-trace of mainOMP.cpp:60 is reported apart. */
+   image needs.  The second search of mainOMP.cpp:60 is reported apart, once
+   per light and hit as the reference performs it, whether or not the device
+   had to run it to know its result. */
 typedef struct PtStats {
     uint64_t primary, shadow, mirror, gi, omp_retrace;
     double ms_total;          /* wall time of the call                     */
