@@ -64,8 +64,8 @@ def pmc_traffic(workload, rays_per_launch):
             vals[t[0]] = float(t[-1][5:])
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
-    # the passes were collected at 16 777 216-ray launches; scale if this run's launches differ
-    scale = rays_per_launch / 16777216.0
+    # the passes were collected at 67 108 864-ray launches (1 024 spp, 256 samples per pass); scale if this run's differ
+    scale = rays_per_launch / 67108864.0
     return round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 * scale / 1e9, 2), os.path.relpath(best, ROOT)
 
 

@@ -399,6 +399,11 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     int batch = 1;
     if (o->gi) {
         size_t cap = fast ? (size_t)PT_FAST_RAYS_PER_PASS : ((size_t)16 << 18);
+        if (fast)
+            if (const char *e = getenv("PT_TUNE_PASS_RAYS")) {
+                const long long k = atoll(e);
+                if (k >= 1 && k <= (long long)(128u << 20)) cap = (size_t)k;
+            }
         batch = (int)(cap / P);
         if (batch < 1) batch = 1;
         if (batch > N) batch = N;

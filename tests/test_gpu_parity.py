@@ -5,6 +5,8 @@ triangle ids, t, u, v, G-buffers, the linear image and the BGR8 frame.
 fp32 GI fast path: ids against the oracle's brute-force nearest hit on
 non-degenerate rays, t within 1e-5 relative, images by RMSE.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -285,6 +287,26 @@ def test_row_bands_of_all_parts_make_the_whole_view(gpu_scenes, host_scenes, nam
         sc.render(**c, part=3, n_parts=3, **kw)
 
 
+def test_fast_path_passes_do_not_change_the_image(gpu_scenes, host_scenes, monkeypatch):
+    """The GI samples of a view are traced in passes of a bounded number of rays (two ray sets, the generator of the
+    next pass running beside the traversal of the current one).  Sums are taken per pixel in sample order, so one
+    pass, three passes and seventeen passes give the same image bit for bit, for both shading models."""
+    c = cam_of(host_scenes("car"))
+    sc = gpu_scenes("car")
+    for model in (device.MODEL_OMP, device.MODEL_MAIN):
+        kw = dict(model=model, gi=True, spp=50, size=96, gi_precision=device.GI_F32_FAST, aov=True)
+        monkeypatch.delenv("PT_TUNE_PASS_RAYS", raising=False)
+        one = sc.render(**c, **kw)
+        assert one["stats"]["gi_trace_launches"] == 1
+        for rays, launches in ((96 * 96 * 20, 3), (96 * 96 * 3, 17)):
+            monkeypatch.setenv("PT_TUNE_PASS_RAYS", str(rays))
+            many = sc.render(**c, **kw)
+            assert many["stats"]["gi_trace_launches"] == launches
+            assert np.array_equal(one["rgb"], many["rgb"]) and np.array_equal(one["bgr"], many["bgr"])
+            assert one["stats"]["gi"] == many["stats"]["gi"] and one["stats"]["shadow"] == many["stats"]["shadow"]
+    monkeypatch.delenv("PT_TUNE_PASS_RAYS", raising=False)
+
+
 def test_blob_upload_and_multi_view(gpu_scenes, host_scenes):
     hs = host_scenes("cbox")
     blob = device.scene_blob(hs.desc())
@@ -420,8 +442,12 @@ def test_full_size_atrium_properties():
         assert not np.array_equal(other["bgr"], a["bgr"])
         again = ds.render(**c, model=device.MODEL_OMP, gi=True, spp=64, gi_precision=device.GI_F32_FAST)
         assert np.array_equal(again["rgb"], a["rgb"]) and np.array_equal(again["bgr"], a["bgr"])
-        # two passes of 64 samples against the fp64 path at the same 128 samples
-        f = ds.render(**c, model=device.MODEL_OMP, gi=True, spp=128, gi_precision=device.GI_F32_FAST)
+        # two passes of 64 samples (16 Mi rays each) against the fp64 path at the same 128 samples
+        os.environ["PT_TUNE_PASS_RAYS"] = str(16 << 20)
+        try:
+            f = ds.render(**c, model=device.MODEL_OMP, gi=True, spp=128, gi_precision=device.GI_F32_FAST)
+        finally:
+            del os.environ["PT_TUNE_PASS_RAYS"]
         e = ds.render(**c, model=device.MODEL_OMP, gi=True, spp=128, gi_precision=device.GI_F64_EXACT)
         assert f["stats"]["gi_trace_launches"] == 2
         for k in ("tri", "t", "ghit", "gnrm"):
