@@ -65,3 +65,24 @@ def test_skipping_rule_never_skips_a_search_that_finds_something(checker, tmp_pa
     assert restatement_differs == 0          # the noted search of the helper is the oracle's search
     assert wrong_skips == 0                  # the rule itself
     assert again < hits // 20                # and it pays: it asks for the second search on few rays
+
+    # rays that start ON the geometry (the hit points of the rays above, exactly and pushed 1e-4 along a coordinate axis
+    # as the shading points are pushed along the normal): the secondary rays of the render path, and the most degenerate start
+    found, mesh, tri = (np.zeros(n, np.int32) for _ in range(3))
+    t, u, v = (np.zeros(n) for _ in range(3))
+    checker.orc_trace.argtypes = [C.c_void_p, C.c_long] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 6
+    big = np.full(n, 3.4028234663852886e38)
+    checker.orc_trace(h, n, src.ctypes.data, d.ctypes.data, big.ctypes.data, 0, found.ctypes.data, mesh.ctypes.data,
+                      tri.ctypes.data, t.ctypes.data, u.ctypes.data, v.ctypes.data)
+    on = found == 1
+    src2 = np.ascontiguousarray(src[on] + t[on, None] * d[on])
+    rng = np.random.default_rng(78)
+    k = len(src2) // 2
+    src2[:k, rng.integers(0, 3)] += 1e-4
+    d2 = rng.normal(size=src2.shape)
+    d2 /= np.linalg.norm(d2, axis=1)[:, None]
+    d2 = np.ascontiguousarray(d2)
+    out2 = np.zeros(5, np.int64)
+    checker.research_check(h, len(src2), src2.ctypes.data, d2.ctypes.data, out2.ctypes.data)
+    print(name, "from the surfaces:", dict(hits=int(out2[0]), searched_again=int(out2[1]), second_found=int(out2[2])))
+    assert out2[0] > len(src2) // 4 and out2[3] == 0 and out2[4] == 0
