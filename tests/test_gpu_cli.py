@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 PTMAIN = os.path.join(ROOT, "pathtracing_amd", "ptmain")
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def read_ppm(path):
     data = open(path, "rb").read()
     parts = data.split(b"\n", 3)
@@ -87,14 +96,14 @@ def test_rm_job_frames_do_not_depend_on_the_number_of_ranks(tmp_path, cbox):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Real Triangles: 2190; Naive: 12440; Optimized: 9073" in r.stdout and "World Size: 1" in r.stdout
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29533", "-m", "pathtracing_amd.rm"] + args +
+                        "127.0.0.1", "--master-port", str(free_port()), "-m", "pathtracing_amd.rm"] + args +
                        ["--out", str(two), "--backend", "gloo"], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "World Size: 2" in r.stdout and r.stdout.count("Elapsed time:") == 5
     # latency mode: both ranks share every view, bands of 8 rows dealt round-robin (48 rows = 6 bands)
     split = tmp_path / "split"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29534", "-m", "pathtracing_amd.rm"] + args +
+                        "127.0.0.1", "--master-port", str(free_port()), "-m", "pathtracing_amd.rm"] + args +
                        ["--out", str(split), "--backend", "gloo", "--split-rows"], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("Elapsed time:") == 5
