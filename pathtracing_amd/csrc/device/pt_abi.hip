@@ -483,6 +483,9 @@ int pt_init(int device) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(PT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     HIPCHK(hipSetDevice(dev));
+    // address of this device's copy of the fixed scratch array (pt_trace_device)
+    if (int rc = static_scratch_setup(dev))
+        return fail(rc, "the address of the library's scratch array could not be taken on device " + std::to_string(dev));
     g_device = dev;
     return PT_OK;
 }
@@ -725,6 +728,23 @@ int pt_trace(PtScene *sc, size_t n, const double *src, const double *dir, const 
     }
     return PT_OK;
 }); }
+
+// No allocation on this path: no hipMalloc / hipFree, no std::vector, no std::string unless the call fails.
+int pt_trace_device(PtScene *sc, size_t n, const double *d_src, const double *d_dir, const double *d_tmin_in,
+                    int32_t *d_found, int32_t *d_mesh, int32_t *d_tri, double *d_t, double *d_u, double *d_v) {
+    if (!sc) return fail(PT_ERR_INVALID, "scene is null");
+    if (g_device < 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not been called");
+    if (n == 0) return PT_OK;
+    if (!d_src || !d_dir || !d_tmin_in || !d_found || !d_mesh || !d_tri || !d_t || !d_u || !d_v)
+        return fail(PT_ERR_INVALID, "pt_trace_device: null array");
+    if (n > PT_STATIC_MAX_RAYS) return fail(PT_ERR_LIMIT, "pt_trace_device: more than 2^24 rays in one call");
+    if (sc->S.ovf_depth > PT_STATIC_DEPTH)
+        return fail(PT_ERR_LIMIT, "pt_trace_device: the scene's fp32 tree is deeper than the fixed scratch stack (62 levels)");
+    int rc = fast_trace_static(sc->S, g_device, n, d_src, d_dir, d_tmin_in, d_found, d_mesh, d_tri, d_t, d_u, d_v, sc->stream);
+    if (rc == PT_ERR_HIP) return fail(rc, std::string("pt_trace_device: ") + hipGetErrorString(hipGetLastError()));
+    if (rc) return fail(rc, "pt_trace_device: no scratch address for this device (pt_init), or a size limit");
+    return PT_OK;
+}
 
 int pt_camera_rays(const PtCamera *cam, int size, double x, double y, double *dir_out) {
     if (g_device < 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not been called");

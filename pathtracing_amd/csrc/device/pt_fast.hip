@@ -680,6 +680,57 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
     return PT_OK;
 }
 
+// ---- the raw query without any allocation ------------------------------------------------
+// Callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops) get the same search with
+// its two scratch buffers -- the queue heads and the traversal overflow stack -- in a fixed array of the code object.
+// Every GPU that loads the library holds its own copy of the array, at its own address, until the process ends.
+// Layout: [0, PT_STATIC_HEAD_BYTES) queue heads; then the overflow stack [wave][entry][lane].
+#define PT_STATIC_HEAD_BYTES (PT_HEAD_WORDS * sizeof(uint32_t))
+#define PT_STATIC_BYTES (PT_STATIC_HEAD_BYTES + (size_t)PT_STATIC_WAVES * PT_STATIC_DEPTH * 64 * sizeof(uint2))
+static __device__ __align__(256) unsigned char scratch[PT_STATIC_BYTES];
+// Device address of `scratch` per device ordinal.  In host code the array's name is only a handle for
+// hipGetSymbolAddress; kernels, memsets and copies take these addresses.
+static unsigned char *g_scratch_ptr[PT_STATIC_MAX_DEVICES];
+
+int static_scratch_setup(int device) {
+    if (device < 0 || device >= PT_STATIC_MAX_DEVICES) return PT_ERR_LIMIT;
+    if (g_scratch_ptr[device]) return PT_OK;
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return PT_ERR_HIP;
+    g_scratch_ptr[device] = (unsigned char *)p;
+    return PT_OK;
+}
+
+// (mesh, triangle of the mesh) of a scene-wide triangle index, the reference's `pii tind` (util/kdtree.cpp:192).
+__global__ void k_tri_to_mesh_local(DevScene S, uint32_t n, int32_t *tri, int32_t *mesh) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int32_t g = tri[k];
+    mesh[k] = g < 0 ? -1 : S.tri_mesh[g];
+    tri[k] = g < 0 ? -1 : S.tri_local[g];
+}
+
+int fast_trace_static(const DevScene &S0, int device, size_t n, const double *src, const double *dir, const double *tmin_in,
+                      int32_t *found, int32_t *mesh, int32_t *tri, double *t, double *u, double *v, hipStream_t s) {
+    if (device < 0 || device >= PT_STATIC_MAX_DEVICES || !g_scratch_ptr[device]) return PT_ERR_NO_DEVICE;
+    if (n > PT_STATIC_MAX_RAYS || S0.ovf_depth > PT_STATIC_DEPTH) return PT_ERR_LIMIT;
+    unsigned char *base = g_scratch_ptr[device];
+    DevScene S = S0;
+    S.ovf = (uint2 *)(base + PT_STATIC_HEAD_BYTES);
+    S.ovf_depth = PT_STATIC_DEPTH;
+    S.ovf_waves = PT_STATIC_WAVES;
+    FQ(hipMemsetAsync(base, 0, PT_STATIC_HEAD_BYTES, s));          // the heads start at zero; the stack is written before it is read
+    const TraceTune tune = trace_tune();
+    unsigned blocks = (unsigned)((n + 63) / 64);
+    if (blocks > PT_STATIC_WAVES) blocks = PT_STATIC_WAVES;
+    hipLaunchKernelGGL(k_trace_fast_f64io, dim3(blocks), dim3(64), (size_t)tune.slots * 64 * sizeof(uint2), s, S, (uint32_t)n,
+                       (uint32_t *)base, src, dir, tmin_in, found, tri, t, u, v, (uint32_t)tune.slots - 1u);
+    hipLaunchKernelGGL(k_tri_to_mesh_local, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, S, (uint32_t)n, tri, mesh);
+    FQ(hipGetLastError());
+    FQ(hipStreamSynchronize(s));
+    return PT_OK;
+}
+
 int fast_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
                int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s) {
     uint32_t *head = nullptr;

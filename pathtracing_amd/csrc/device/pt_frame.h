@@ -93,3 +93,13 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
             uint64_t *work);
 int fast_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
                int32_t *found, int32_t *tri, double *t, double *u, double *v, hipStream_t s);
+// The same search on device-resident rays with its scratch (queue heads, overflow stack) in a fixed array of the
+// code object: no allocation.  Sizes of that array: waves of a launch, stack entries per lane (>= fp32 tree depth + 2),
+// the most rays one call takes, and the device ordinals the library keeps an address for.
+#define PT_STATIC_WAVES 1024u
+#define PT_STATIC_DEPTH 64u
+#define PT_STATIC_MAX_RAYS ((size_t)1 << 24)
+#define PT_STATIC_MAX_DEVICES 64
+int static_scratch_setup(int device);      // once per device, with that device current (pt_init)
+int fast_trace_static(const DevScene &S, int device, size_t n, const double *src, const double *dir, const double *tmin_in,
+                      int32_t *found, int32_t *mesh, int32_t *tri, double *t, double *u, double *v, hipStream_t s);

@@ -43,7 +43,7 @@ class PtSceneInfo(C.Structure):
 
 EXPORTS = ("pt_scene_info", "pt_init", "pt_shutdown", "pt_last_error", "pt_version", "pt_scene_upload", "pt_scene_free",
            "pt_scene_blob_size", "pt_scene_blob_write", "pt_scene_upload_blob", "pt_render_view",
-           "pt_render_view_device", "pt_render_views", "pt_trace", "pt_camera_rays", "pt_hemisphere_samples")
+           "pt_render_view_device", "pt_render_views", "pt_trace", "pt_trace_device", "pt_camera_rays", "pt_hemisphere_samples")
 
 _lib = None
 
@@ -71,6 +71,7 @@ def lib():
         L.pt_render_views.argtypes = [C.c_void_p, C.POINTER(PtCamera), C.c_size_t, C.c_uint32, C.c_uint32,
                                       C.POINTER(PtOptions), C.c_void_p, C.POINTER(PtStats)]
         L.pt_trace.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 6
+        L.pt_trace_device.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9
         L.pt_camera_rays.argtypes = [C.POINTER(PtCamera), C.c_int, C.c_double, C.c_double, C.c_void_p]
         L.pt_hemisphere_samples.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         _lib = L
@@ -177,6 +178,12 @@ class DeviceScene:
                               found.ctypes.data, mesh.ctypes.data, tri.ctypes.data, t.ctypes.data, u.ctypes.data,
                               v.ctypes.data), "pt_trace")
         return {"found": found, "mesh": mesh, "tri": tri, "t": t, "u": u, "v": v}
+
+    def trace_device(self, n, d_src, d_dir, d_tmin_in, d_found, d_mesh, d_tri, d_t, d_u, d_v):
+        """pt_trace_device: the fp32 nearest-hit search on n rays in device memory (arguments are device addresses);
+        allocates nothing."""
+        _check(lib().pt_trace_device(self._h, n, d_src, d_dir, d_tmin_in, d_found, d_mesh, d_tri, d_t, d_u, d_v),
+               "pt_trace_device")
 
     def close(self):
         if self._h:
