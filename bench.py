@@ -111,6 +111,25 @@ def atrium_views(cam):
     return views
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` started as one plain process: start the N ranks (one per GPU) as a
+    torch.distributed.run child process -- a child, not an exec, and before this process has touched a GPU or
+    imported torch -- pass its output through (rank 0 prints the JSON line) and return its exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +143,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path with every rank on GPU 0 and the exchanges staged through host memory")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, meet over gloo, print a JSON line with the world size and stop: checks the "
+                         "launcher on a machine without a GPU")
     a = ap.parse_args()
     if a.workload == "room":
         a.rb = True
@@ -131,10 +153,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one process per GPU)")
-        a.gpus = world
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus))
+    a.gpus = world
+    if a.rendezvous_only:
+        import torch
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+        seen = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "rank_sum": float(seen[0])}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     import torch
     import torch.distributed as dist

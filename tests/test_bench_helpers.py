@@ -54,3 +54,17 @@ def test_supplied_sponza_directory_becomes_the_default_workload(tmp_path, monkey
     assert st["triangles"] == 2190 and len(views) == 16              # no camera path supplied: 16 angles at the scene camera
     os.remove(root / "scenes" / "sponza" / "cbox2.txt")
     assert bench.default_workload() == "atrium"                      # mesh missing again
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as one plain process (no WORLD_SIZE in the environment, the way the round driver starts
+    it) launches the two ranks itself as a child process and passes rank 0's line through; no GPU is needed for the
+    rendezvous-only form."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert lines == [{"rendezvous_only": True, "n_gpus": 2, "rank_sum": 3.0}]

@@ -115,3 +115,28 @@ def test_rm_job_frames_do_not_depend_on_the_number_of_ranks(tmp_path, cbox):
         want = ds.render(list(cams[v].eye), cams[v].angle, cams[v].zoom, size=48, aov=False, gi=True, spp=4,
                          model=device.MODEL_OMP, view=v, gi_precision=device.GI_F32_FAST)["bgr"]
         assert np.array_equal(a, want), v
+
+
+def test_bench_with_two_ranks_started_by_itself(cbox):
+    """`python bench.py --gpus 2` without a launcher around it (how the round driver starts it) runs two ranks -- here the
+    gloo rehearsal, both on this one GPU -- and rank 0 prints one line for the whole job; the one-rank line has the
+    same fields."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    lines = {}
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "gloo", "--workload", "cbox",
+                            "--spp", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+        assert len(out) == 1, r.stdout
+        lines[n] = out[0]
+    one, two = lines[1], lines[2]
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["steps"] == 3 and two["scaling"] == "weak"
+    assert set(one) == set(two)
+    assert two["config"]["views_per_step"] == 2 and two["value"] > 0 and two["roofline"]["frac"] > 0
+    # weak scaling: every rank renders the same cameras, so the job traced twice the rays
+    rays = lambda j: j["value"] * 1e6 * j["ms_per_step"] * 1e-3 * j["steps"]
+    assert abs(rays(two) / rays(one) - 2.0) < 0.02
