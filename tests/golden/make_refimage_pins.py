@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Pins of the oracle against frames the reference itself rendered (build container only).
+
+The reference ships 512 x 512 JPEG frames of its own renderer under ml/data/<SCENE>/ (training data of its
+denoiser): <SCENE>dif (no -gi), <SCENE>4ssp and <SCENE>4096ssp (-gi, noisy and converged), 320 each = 20 path
+positions x 16 angles.  This script finds which of them the shipped scene files and camera path reproduce and
+stores those, subsampled, as a fixture; tests/test_refimage_pins.py then holds the oracle (CPU) and the HIP
+path (GPU) against them.
+
+What was found for cbox (scenes/cbox, scenes/paths/cboxpath.txt; frame k = position k // 16, angle index k % 16):
+
+* CBOXdif/cbox<k>.jpg is the main.cpp shading model (shadow rays, mirror bounce weighted 0.6, main.cpp:41-78)
+  without -gi, at the ABSOLUTE view angle 22.5 deg * (k % 16) from the path position -- an earlier form of
+  renderParallel's camera than the shipped one (mainOMP.cpp:164-165 adds -acos(-unit(a, 0, c).x)).
+* CBOX4096ssp/cbox<k>.jpg is the mainOMP.cpp model with -gi (mainOMP.cpp:37-136: no shadows, mirror bounce
+  weighted 1, 2 * mclr * GI / N) at the shipped camera of mainOMP.cpp:164-165.
+* Both hold for the 304 frames of positions 1..19; the 16 frames of position 0 were rendered from some other
+  place and are left out.
+* ml/data/CAR/* was rendered from an arrangement of the car scene that differs from the shipped scenes/car
+  (the room is smaller and the car fills more of the frame at every position; a grid + simplex search over the
+  eye position leaves an RMSE above 20 / 255), so no car frame can serve as a pin.
+
+A size-S render samples the image plane at j / S, so pixel (i, j) of a 32 x 32 render is exactly pixel
+(16 i, 16 j) of the 512 x 512 frame: the fixture keeps every 16th pixel of every 16th row.
+
+Usage: python tests/golden/make_refimage_pins.py   (needs /root/reference and Pillow; writes
+tests/golden/refimages_cbox.npz and refimages_cbox.json)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/ml/data/CBOX"
+STRIDE, SIDE = 16, 32
+GI_SPP = 1024
+
+
+def path_positions(path_file):
+    lines = open(path_file).read().split("\n")
+    n = int(lines[0])
+    return [tuple(float(x) for x in lines[1 + i].split()) for i in range(n)]
+
+
+def shipped_angle(pos, j):
+    """mainOMP.cpp:164-165."""
+    a, c = pos[0], pos[2]
+    return -np.arccos(-(a / np.sqrt(a * a + c * c))) + np.pi / 180.0 * (22.5 * j)
+
+
+def absolute_angle(j):
+    return np.pi / 180.0 * (22.5 * j)
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def main():
+    from PIL import Image
+
+    from oracle import ptoracle as po
+    orc = po.OracleScene(os.path.join(ROOT, "scenes", "cbox.ptscene"))
+    zoom = orc.camera()["zoom"]
+    pos = path_positions(os.path.join(ROOT, "scenes", "paths", "cboxpath.txt"))
+
+    def ref(sub, k):
+        im = np.asarray(Image.open(os.path.join(REF, sub, f"cbox{k}.jpg")).convert("RGB"))
+        assert im.shape == (512, 512, 3)
+        return im[::STRIDE, ::STRIDE, ::-1].copy()          # BGR, as the frames of the render path
+
+    rows, keep, dif, gi = [], [], [], []
+    for k in range(320):
+        p, j = divmod(k, 16)
+        d_ref, g_ref = ref("CBOXdif", k), ref("CBOX4096ssp", k)
+        d = orc.render(eye=list(pos[p]), angle=absolute_angle(j), zoom=zoom, model=po.MODEL_MAIN, gi=False, size=SIDE,
+                       threads=8, aov=False)["bgr"]
+        g = orc.render(eye=list(pos[p]), angle=shipped_angle(pos[p], j), zoom=zoom, model=po.MODEL_OMP, gi=True, spp=GI_SPP,
+                       size=SIDE, threads=8, aov=False, view=k)["bgr"]
+        row = {"k": k, "position": p, "angle_index": j, "dif_rmse": round(rmse(d, d_ref), 3),
+               "gi_rmse": round(rmse(g, g_ref), 3), "gi_mean_diff": round(float(g.mean()) - float(g_ref.mean()), 3)}
+        rows.append(row)
+        if p >= 1:
+            keep.append(k); dif.append(d_ref); gi.append(g_ref)
+        print(row, flush=True)
+    out = os.path.join(ROOT, "tests", "golden", "refimages_cbox.npz")
+    np.savez_compressed(out, k=np.array(keep, np.int32), dif=np.array(dif, np.uint8), gi4096=np.array(gi, np.uint8))
+    kept = [r for r in rows if r["position"] >= 1]
+    summary = {"source": "ml/data/CBOX/{CBOXdif,CBOX4096ssp}/cbox<k>.jpg of the reference, every 16th pixel of every 16th row, BGR",
+               "oracle_gi_spp": GI_SPP, "frames_kept": len(kept),
+               "dif_rmse_max_kept": max(r["dif_rmse"] for r in kept), "gi_rmse_max_kept": max(r["gi_rmse"] for r in kept),
+               "gi_mean_diff_max_abs_kept": max(abs(r["gi_mean_diff"]) for r in kept),
+               "dif_rmse_min_position0": min(r["dif_rmse"] for r in rows if r["position"] == 0),
+               "gi_rmse_min_position0": min(r["gi_rmse"] for r in rows if r["position"] == 0),
+               "frames": rows}
+    json.dump(summary, open(os.path.join(ROOT, "tests", "golden", "refimages_cbox.json"), "w"), indent=0)
+    print({k: v for k, v in summary.items() if k != "frames"})
+
+
+if __name__ == "__main__":
+    main()
