@@ -17,12 +17,13 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Wall
 $(DEVDIR)/pt_abi.o $(DEVDIR)/pt_exact.o $(DEVDIR)/pt_refine.o: CONTRACT := -ffp-contract=off
 $(DEVDIR)/pt_fast.o: CONTRACT := -ffp-contract=fast
 
-all: host device cli oracle
+all: host device cli oracle tools
 
 host: $(PKG)/libpthost.so
 device: $(PKG)/libptamd.so
 cli: $(PKG)/ptmain
 oracle: oracle/libptoracle.so
+tools: tools/ta_rate
 
 $(PKG)/libpthost.so: $(HOSTSRC) $(PKG)/csrc/host/scene.hpp include/pathtracing_host.h include/pathtracing_amd.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOSTSRC)
@@ -36,10 +37,14 @@ $(PKG)/libptamd.so: $(DEVOBJ)
 $(PKG)/ptmain: $(PKG)/csrc/cli/ptmain.cpp $(PKG)/libpthost.so $(PKG)/libptamd.so
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG) -lpthost -lptamd -Wl,-rpath,'$$ORIGIN' -L$(ROCM)/lib -Wl,-rpath,$(ROCM)/lib
 
+# load-rate micro-benchmark that bench.py runs beside its timings (the physical ceiling of the traversal kernel)
+tools/ta_rate: tools/ta_rate.hip
+	$(HIPCC) -O3 --offload-arch=gfx950 -o $@ $<
+
 oracle/libptoracle.so: oracle/pt_oracle.c
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(DEVOBJ) $(PKG)/libpthost.so $(PKG)/libptamd.so $(PKG)/ptmain oracle/libptoracle.so
+	rm -f $(DEVOBJ) $(PKG)/libpthost.so $(PKG)/libptamd.so $(PKG)/ptmain oracle/libptoracle.so tools/ta_rate
 
-.PHONY: all host device cli oracle clean
+.PHONY: all host device cli oracle tools clean

@@ -21,6 +21,13 @@ run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum && \
 run fetch FETCH_SIZE && \
 run write WRITE_SIZE && \
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_BUSY_avr
-python3 tools/pmc_summary.py "$OUT" "k_trace_closest<false>" > "$OUT/pmc_k_trace_closest.txt"
-python3 tools/pmc_summary.py "$OUT" "k_primary_exact" > "$OUT/pmc_k_primary_exact.txt"
+# header lines: the digest of the kernel sources the counters belong to (bench.py flags a collection as stale when the
+# sources have changed since) and the rays one launch processed
+HDR=$(python3 -c "
+import json, bench
+j = json.load(open('$OUT/bench_under_trace.json'))
+print('# kernel_source_hash', bench.kernel_source_hash())
+print('# rays_per_launch', j['roofline']['rays_per_launch'])")
+{ echo "$HDR"; python3 tools/pmc_summary.py "$OUT" "k_trace_closest<false>"; } > "$OUT/pmc_k_trace_closest.txt"
+{ echo "$HDR"; python3 tools/pmc_summary.py "$OUT" "k_primary_exact"; } > "$OUT/pmc_k_primary_exact.txt"
 ls "$OUT/trace"

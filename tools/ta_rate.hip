@@ -1,10 +1,12 @@
 // Micro-benchmark: throughput of fully divergent per-lane loads of 4, 8 and 16 bytes that hit in L1, in L2 or
-// beyond (what bounds the kd traversal).  Prints lane-loads per clock per CU.
-//   hipcc -O3 --offload-arch=gfx950 -o /tmp/ta_rate tools/ta_rate.hip && /tmp/ta_rate
-// MI355X: 8 KB (L1) 1.86, 1 MB (L2) 0.45, 64 MB 0.10 -- for every load width.
+// beyond (what bounds the kd traversal).  Prints lane-loads per clock per CU (clock taken as 2.4 GHz, 256 CUs).
+//   make tools/ta_rate && tools/ta_rate [--json]
+// --json: one line {"l1": .., "l2": .., "beyond": ..} with the 16-byte figures, which bench.py reads in the same run
+// as its timings.  MI355X: 8 KB (L1) 1.86, 1 MB (L2) 0.45, 64 MB 0.10 -- for every load width.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstring>
 
 template <int BYTES>
 __global__ void __launch_bounds__(256) k_gather(const char *base, uint32_t mask, int iters, uint32_t *sink) {
@@ -35,9 +37,12 @@ double run(const char *d, uint32_t slots, uint32_t *sink) {
     return (double)blocks * 256 * iters / (ms * 1e-3);              // lane-loads per second
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const bool json = argc > 1 && std::strcmp(argv[1], "--json") == 0;
     uint32_t *sink;
     if (hipMalloc(&sink, 4) != hipSuccess) return 1;
+    double r16s[3];
+    int level = 0;
     for (uint32_t kb : {8u, 1024u, 65536u}) {
         const uint32_t slots = kb * 1024u / 16u;
         char *d;
@@ -45,8 +50,10 @@ int main() {
         (void)hipMemset(d, 1, (size_t)slots * 16);
         const double r4 = run<4>(d, slots, sink), r8 = run<8>(d, slots, sink), r16 = run<16>(d, slots, sink);
         const double per = 256.0 * 2.4e9;                             // CUs x clock
-        std::printf("%6u KB: 4 B %.2f  8 B %.2f  16 B %.2f lane-loads/clk/CU\n", kb, r4 / per, r8 / per, r16 / per);
+        if (!json) std::printf("%6u KB: 4 B %.2f  8 B %.2f  16 B %.2f lane-loads/clk/CU\n", kb, r4 / per, r8 / per, r16 / per);
+        r16s[level++] = r16 / per;
         (void)hipFree(d);
     }
+    if (json) std::printf("{\"l1\": %.4f, \"l2\": %.4f, \"beyond\": %.4f}\n", r16s[0], r16s[1], r16s[2]);
     return 0;
 }
