@@ -264,6 +264,8 @@ bool decode_jpeg_file(const std::string &path, Texture &out) {
                 comp[k].h = seg[7 + 3 * k] >> 4; comp[k].v = seg[7 + 3 * k] & 15;
                 comp[k].tq = seg[8 + 3 * k];
                 if (comp[k].h < 1 || comp[k].h > 2 || comp[k].v < 1 || comp[k].v > 2 || comp[k].tq > 3) return false;
+                for (int q = 0; q < k; q++)
+                    if (comp[q].id == comp[k].id) return false;         // component ids must differ
             }
             have_frame = true;
         } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
@@ -274,14 +276,16 @@ bool decode_jpeg_file(const std::string &path, Texture &out) {
         } else if (m == 0xEE) {
             if (seg_end - seg >= 12 && std::memcmp(seg, "Adobe", 5) == 0) adobe_transform = seg[11];
         } else if (m == 0xDA) {                                 // scan: entropy-coded data follows
-            if (!have_frame) return false;
+            if (!have_frame || seg_end - seg < 1) return false;
             const int ns = seg[0];
             if (ns != (int)comp.size() || seg_end - seg < 1 + 2 * ns + 3) return false;    // one interleaved scan
+            std::vector<char> named(comp.size(), 0);
             for (int k = 0; k < ns; k++) {
                 const int cid = seg[1 + 2 * k];
                 Component *c = nullptr;
                 for (auto &q : comp) if (q.id == cid) c = &q;
-                if (!c) return false;
+                if (!c || named[c - comp.data()]) return false;         // unknown component, or one named twice
+                named[c - comp.data()] = 1;
                 c->td = seg[2 + 2 * k] >> 4; c->ta = seg[2 + 2 * k] & 15;
                 if (c->td > 3 || c->ta > 3 || !dc[c->td].present || !ac[c->ta].present || !have_q[c->tq]) return false;
             }

@@ -32,7 +32,9 @@ struct Bits {
         acc >>= k; n -= k;
         return v;
     }
-    void align() { acc = 0; n = 0; }
+    // to the next byte boundary: drop the rest of the current byte and hand back the whole bytes that get() / peek()
+    // have already pulled into the accumulator
+    void align() { n -= n % 8; p -= n / 8; acc = 0; n = 0; }
     // the next k bits without consuming them (zero-padded past the end); k <= 16
     uint32_t peek(int k) {
         while (n < k && p < end) { acc |= (uint32_t)*p++ << n; n += 8; }
@@ -149,6 +151,7 @@ bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, size_t exp
             for (;;) {
                 const int sym = lit.decode(b);
                 if (sym < 0) return false;
+                if (out.size() > expect + 64) return false;            // checked while expanding, not only per block
                 if (sym < 256) { out.push_back((uint8_t)sym); continue; }
                 if (sym == 256) break;
                 if (sym > 285) return false;

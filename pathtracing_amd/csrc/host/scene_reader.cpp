@@ -92,6 +92,32 @@ bool load_ppm(const std::string &path, Texture &out) {
     return ok;
 }
 
+// Index sanity of one mesh, for both readers: the kd build, the flattening and the device code index these pools
+// without checks.
+static bool check_mesh_indices(const Mesh &mesh, const std::string &what) {
+    for (const Triangle &tr : mesh.tris) {
+        for (int k = 0; k < 3; k++) {
+            if (tr.vi[k] < 0 || tr.vi[k] >= (int)mesh.vert.size() || tr.ni[k] < 0 || tr.ni[k] >= (int)mesh.norm.size() ||
+                tr.ti[k] < -1 || tr.ti[k] >= (int)mesh.uv.size()) {
+                set_error(what + ": face index out of range");
+                return false;
+            }
+            if (tr.tm != -99999 && tr.tm < 0 && tr.ti[k] < 0) {
+                set_error(what + ": per-hit textured face without texture coordinates");
+                return false;
+            }
+        }
+        if (tr.tm != -99999) {
+            const long long k = tr.tm >= 0 ? (long long)tr.tm : -((long long)tr.tm + 1);
+            if (k >= (long long)mesh.tmaps.size()) {
+                set_error(what + ": texture index out of range");
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
 bool read_scene_dir(const std::string &dir, const std::string &texture_dir, Scene &sc) {
     std::ifstream master(dir + "/master.txt");
     if (!master) { set_error("cannot open " + dir + "/master.txt"); return false; }
@@ -186,19 +212,7 @@ bool read_scene_dir(const std::string &dir, const std::string &texture_dir, Scen
                 default: break;
             }
         }
-        // Index sanity: the device code indexes these pools without checks.
-        for (const Triangle &tr : mesh.tris)
-            for (int k = 0; k < 3; k++) {
-                if (tr.vi[k] < 0 || tr.vi[k] >= (int)mesh.vert.size() || tr.ni[k] < 0 || tr.ni[k] >= (int)mesh.norm.size() ||
-                    tr.ti[k] < -1 || tr.ti[k] >= (int)mesh.uv.size()) {
-                    set_error("mesh file " + fn + ": face index out of range");
-                    return false;
-                }
-                if (tr.tm != -99999 && tr.tm < 0 && tr.ti[k] < 0) {
-                    set_error("mesh file " + fn + ": per-hit textured face without texture coordinates");
-                    return false;
-                }
-            }
+        if (!check_mesh_indices(mesh, "mesh file " + fn)) return false;
         sc.meshes.push_back(std::move(mesh));
     }
     return true;
@@ -259,6 +273,9 @@ bool load_packed(const std::string &path, Scene &sc) {
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) { set_error("cannot open " + path); return false; }
     Reader r{f};
+    std::fseek(f, 0, SEEK_END);
+    const long long file_bytes = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
     char magic[8];
     r.get(magic, 8);
     if (!r.ok || std::memcmp(magic, "PTSCENE1", 8) != 0) {
@@ -287,6 +304,9 @@ bool load_packed(const std::string &path, Scene &sc) {
         r.get(m.albedo.data(), 24);
         uint32_t nv = r.u32(), nn = r.u32(), nt = r.u32(), ntri = r.u32(), ntex = r.u32();
         if (!r.ok) break;
+        // counts that the file cannot hold are damage, not sizes to allocate
+        if ((long long)nv * 24 + (long long)nn * 24 + (long long)nt * 16 + (long long)ntri * (long long)sizeof(Triangle) +
+                (long long)ntex * 8 > file_bytes) { r.ok = false; break; }
         m.vert.resize(nv); m.norm.resize(nn); m.uv.resize(nt); m.tris.resize(ntri);
         r.get(m.vert.data(), (size_t)nv * 24);
         r.get(m.norm.data(), (size_t)nn * 24);
@@ -295,7 +315,7 @@ bool load_packed(const std::string &path, Scene &sc) {
         for (uint32_t k = 0; r.ok && k < ntex; k++) {
             Texture t;
             t.rows = (int32_t)r.u32(); t.cols = (int32_t)r.u32();
-            if (!r.ok || t.rows <= 0 || t.cols <= 0) { r.ok = false; break; }
+            if (!r.ok || t.rows <= 0 || t.cols <= 0 || (long long)t.rows * t.cols * 3 > file_bytes) { r.ok = false; break; }
             t.bgr.resize((size_t)t.rows * t.cols * 3);
             r.get(t.bgr.data(), t.bgr.size());
             m.tmaps.push_back(std::move(t));
@@ -304,6 +324,8 @@ bool load_packed(const std::string &path, Scene &sc) {
     }
     std::fclose(f);
     if (!r.ok) { set_error(path + ": truncated or corrupt PTSCENE1 file"); return false; }
+    for (size_t i = 0; i < sc.meshes.size(); i++)
+        if (!check_mesh_indices(sc.meshes[i], path + ": mesh " + std::to_string(i))) return false;
     return true;
 }
 

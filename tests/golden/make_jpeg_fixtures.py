@@ -68,5 +68,25 @@ for name, (mode, kw) in png_cases.items():
     path = os.path.join(here, name + ".png")
     im.save(path, format="PNG", **kw)
     expected[name] = np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1].copy()
+# A deflate stream in which stored blocks FOLLOW Huffman blocks at arbitrary bit positions: a sync flush ends the
+# current block and emits an empty stored block, which starts at the next byte boundary.  Written by hand (filter
+# type 0 on every row), because an encoder never produces this by itself.
+import struct
+import zlib
+img = picture(45, 37)
+co = zlib.compressobj(6)
+stream = b""
+for y in range(45):
+    stream += co.compress(b"\0" + img[y].tobytes())
+    if y % 5 == 4:
+        stream += co.flush(zlib.Z_FULL_FLUSH if y == 24 else zlib.Z_SYNC_FLUSH)
+stream += co.flush()
+def chunk(kind, data):
+    return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data))
+path = os.path.join(here, "png_flushed.png")
+open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 37, 45, 8, 2, 0, 0, 0)) + chunk(b"IDAT", stream) +
+                       chunk(b"IEND", b""))
+expected["png_flushed"] = np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1].copy()
+assert np.array_equal(expected["png_flushed"], img[:, :, ::-1])
 np.savez_compressed(os.path.join(here, "expected.npz"), **expected)
 print({k: v.shape for k, v in expected.items()})

@@ -110,7 +110,7 @@ def test_image_decoders_against_fixtures(tmp_path):
     d = os.path.join(ROOT, "tests", "golden", "jpeg")
     expected = np.load(os.path.join(d, "expected.npz"))
     assert len(expected.files) >= 8
-    assert sum(n.startswith("png_") for n in expected.files) >= 7
+    assert sum(n.startswith("png_") for n in expected.files) >= 8
     for name in expected.files:
         got = host.decode_image(os.path.join(d, name + (".png" if name.startswith("png_") else ".jpg")))
         assert got.shape == expected[name].shape, name
@@ -239,3 +239,35 @@ def test_ctypes_mirror_matches_the_c_header(tmp_path):
     for n in names:
         cls = getattr(device, n, None) or getattr(host, n)
         assert ctypes.sizeof(cls) == int(out[n]), n
+
+
+def test_damaged_packed_scene_is_refused(tmp_path):
+    """A .ptscene whose triangle records point outside their pools (or whose counts the file cannot hold) is refused by
+    the reader itself: the kd build and the flattening index the pools unchecked."""
+    import struct
+    raw = bytearray(open(scene_path("cbox"), "rb").read())
+    n_light = struct.unpack_from("<I", raw, 8 + 56 + 24)[0]
+    at = 8 + 56 + 24 + 4 + n_light * 60
+    assert struct.unpack_from("<I", raw, at)[0] == 1                          # one mesh
+    at += 4 + 24
+    nv, nn, nt, ntri, ntex = struct.unpack_from("<5I", raw, at)
+    assert ntri == 2190 and ntex == 7
+    tris = at + 20 + nv * 24 + nn * 24 + nt * 16                              # 44-byte records: vi[3] ni[3] ti[3] tm reft
+
+    def load(edit):
+        bad = bytearray(raw)
+        edit(bad)
+        p = tmp_path / "damaged.ptscene"
+        p.write_bytes(bad)
+        return host.HostScene.from_packed(str(p))
+
+    load(lambda b: None)                                                      # the undamaged copy loads
+    for what, edit in (
+            ("face index", lambda b: struct.pack_into("<i", b, tris + 44 * 5, 10 ** 9)),                 # vi[0] of triangle 5
+            ("face index", lambda b: struct.pack_into("<i", b, tris + 44 * 100 + 12, -3)),               # ni[0] negative
+            ("face index", lambda b: struct.pack_into("<i", b, tris + 44 * 7 + 24, nt)),                 # ti[0] == pool size
+            ("texture index", lambda b: struct.pack_into("<i", b, tris + 44 * 9 + 36, ntex)),            # tm one past the end
+            ("texture index", lambda b: struct.pack_into("<i", b, tris + 44 * 9 + 36, -(ntex + 1) - 1)), # per-hit form of the same
+            ("corrupt", lambda b: struct.pack_into("<I", b, at + 12, 0x7FFFFFFF))):                      # triangle count
+        with pytest.raises(host.HostError, match=what):
+            load(edit)
