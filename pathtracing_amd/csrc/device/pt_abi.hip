@@ -272,6 +272,16 @@ int upload(const PtSceneDesc *d, PtScene **out) {
         sc->dev_bytes += bytes;
         S.ovf = (uint2 *)p;
     }
+    {
+        // overflow of the fp64 search's stack: beyond its LDS ring a lane needs at most one entry per tree level
+        S.ovf64_entries = (uint32_t)depth + 2u;
+        void *p = nullptr;
+        size_t bytes = (size_t)PT_EXACT_WAVES * S.ovf64_entries * 64 * 3 * sizeof(double);
+        if (hipMalloc(&p, bytes) != hipSuccess) return bail(fail(PT_ERR_OOM, "out of device memory (fp64 stack overflow)"));
+        sc->owned.push_back(p);
+        sc->dev_bytes += bytes;
+        S.ovf64 = (double *)p;
+    }
     UP(dev_copy(sc, tgeo.data(), tgeo.size(), &S.triGeo));
     UP(dev_copy(sc, tng.data(), tng.size(), &S.triNgF));
     UP(dev_copy(sc, d->refs, (size_t)d->n_ref, &S.refId));
@@ -320,6 +330,8 @@ int upload(const PtSceneDesc *d, PtScene **out) {
         UP(dev_copy(sc, lf.data(), lf.size(), &S.lightsF));
     }
 #undef UP
+    S.any_mirror = 0;
+    for (uint32_t t = 0; t < d->n_tri; t++) S.any_mirror |= d->tri_reft[t] != 0;
     S.n_light = (int32_t)d->n_light; S.n_node = (int32_t)d->n_node; S.n_ref = (int32_t)d->n_ref; S.n_tri = (int32_t)d->n_tri;
     for (int k = 0; k < 3; k++) {
         S.bg[k] = d->background[k];
@@ -367,6 +379,8 @@ int ensure_workspace(PtScene *sc, int size, int batch, bool fast, int nsub) {
     WS(ws_alloc(ws, P * nsub, &ws.B.found));
     WS(ws_alloc(ws, P * nsub, &ws.B.tri));
     WS(ws_alloc(ws, P * nsub * 3, &ws.B.tuv));
+    WS(ws_alloc(ws, P * nsub, &ws.B.mirror));
+    WS(ws_alloc(ws, P * nsub * 3, &ws.B.mdir));
     if (fast) WS(fast_alloc(ws.Q, P, batch, ws_alloc_cb, &ws));
 #undef WS
     ws.size = size; ws.batch = batch; ws.nsub = nsub;

@@ -1,6 +1,7 @@
 // fp64 device functions with the reference's exact semantics: ray/triangle
 // test, kd search, surface properties, lights, castRay.  A thread owns a ray
-// from search to radiance; the traversal stack is a per-lane array.
+// from search to radiance; the traversal stack is a per-lane ring in LDS that
+// spills its oldest entry to a column in device memory when it is full.
 #pragma once
 #include <float.h>
 
@@ -8,6 +9,60 @@
 #include "pt_vec.h"
 
 #define PT_STACK_MAX 64   // >= tree depth, checked when the scene is uploaded
+
+// Stack of search() (util/kdtree.cpp:203-208,223-250): entries (node, ent, ext).  The newest PT_RING64 entries of a
+// lane live in LDS, laid out [entry][lane] per field (8-byte accesses at stride 8: no bank conflicts whatever the
+// lanes' depths); when the ring is full the oldest entry moves to the lane's column of the block's overflow region
+// in device memory and is popped from there once the ring has run empty.  The stack never holds more than one
+// entry per tree level, and the overflow region is sized for the tree's depth at upload, so nothing is ever dropped.
+#define PT_RING64 8
+#define PT_RING64_LDS_BYTES (PT_RING64 * 64 * 20)
+struct StackD {
+    double *ent, *ext;        // LDS, this lane's column; entry k at [k * 64]
+    uint32_t *node;
+    double *ovf;              // device memory, this lane's column; field f of entry e at [(3 * e + f) * 64]
+    uint32_t top, cnt, novf;
+    PT_DEV void clear() { top = 0; cnt = 0; novf = 0; }
+    PT_DEV uint32_t size() const { return cnt + novf; }
+    PT_DEV void push(int n, double e, double x) {
+        if (cnt == PT_RING64) {                      // full: `top` is also the oldest entry's slot
+            double *o = ovf + (size_t)novf * 192;
+            o[0] = __longlong_as_double((long long)node[top * 64]); o[64] = ent[top * 64]; o[128] = ext[top * 64];
+            novf++; cnt--;
+        }
+        node[top * 64] = (uint32_t)n; ent[top * 64] = e; ext[top * 64] = x;
+        top = (top + 1u) & (PT_RING64 - 1u);
+        cnt++;
+    }
+    PT_DEV void pop(int &n, double &e, double &x) {  // size() > 0
+        if (cnt == 0) {
+            novf--;
+            const double *o = ovf + (size_t)novf * 192;
+            n = (int)__double_as_longlong(o[0]); e = o[64]; x = o[128];
+            return;
+        }
+        top = (top - 1u) & (PT_RING64 - 1u);
+        cnt--;
+        n = (int)node[top * 64]; e = ent[top * 64]; x = ext[top * 64];
+    }
+    // smallest `ent` among the entries left on the stack
+    PT_DEV double min_ent() const {
+        double m = DBL_MAX;
+        for (uint32_t i = 0; i < cnt; i++) { const double e = ent[((top - 1u - i) & (PT_RING64 - 1u)) * 64]; if (e < m) m = e; }
+        for (uint32_t i = 0; i < novf; i++) { const double e = ovf[(size_t)i * 192 + 64]; if (e < m) m = e; }
+        return m;
+    }
+};
+// The calling wave's stack: `lds` is the block's PT_RING64_LDS_BYTES of shared memory (one wave per block).
+PT_DEV StackD make_stack(const DevScene &S, double *lds) {
+    const uint32_t lane = threadIdx.x & 63u;
+    StackD st;
+    st.ent = lds + lane; st.ext = lds + PT_RING64 * 64 + lane;
+    st.node = (uint32_t *)(lds + 2 * PT_RING64 * 64) + lane;
+    st.ovf = S.ovf64 + (size_t)blockIdx.x * S.ovf64_entries * 192 + lane;
+    st.clear();
+    return st;
+}
 
 struct HitD { int32_t tri; double tmin, u, v; };
 
@@ -42,17 +97,23 @@ PT_DEV bool tri_intersect(const D3 &v0, const D3 &ba, const D3 &ca, const RayD &
     return true;
 }
 
-// Box::intersect, util/kdtree.cpp:30-49 (ent/ext come from the x and y slabs only).
+// Box::intersect, util/kdtree.cpp:30-49 (ent/ext come from the x and y slabs only).  The reciprocal direction and the
+// sign bits of the Ray (util/polygonMesh.cpp:14-19) are only ever read here, so they are formed here -- the same
+// divisions -- instead of being carried through the search in registers.
 PT_DEV bool box_intersect(const double lo[3], const double hi[3], const RayD &r, double &ent, double &ext) {
-    double tmin = ((r.sx ? hi[0] : lo[0]) - r.src.x) * r.inv.x;
-    double tmax = ((r.sx ? lo[0] : hi[0]) - r.src.x) * r.inv.x;
-    double ymin = ((r.sy ? hi[1] : lo[1]) - r.src.y) * r.inv.y;
-    double ymax = ((r.sy ? lo[1] : hi[1]) - r.src.y) * r.inv.y;
+    const double ix = 1.0 / r.dir.x, iy = 1.0 / r.dir.y;
+    const bool sx = __double_as_longlong(r.dir.x) < 0, sy = __double_as_longlong(r.dir.y) < 0;
+    double tmin = ((sx ? hi[0] : lo[0]) - r.src.x) * ix;
+    double tmax = ((sx ? lo[0] : hi[0]) - r.src.x) * ix;
+    double ymin = ((sy ? hi[1] : lo[1]) - r.src.y) * iy;
+    double ymax = ((sy ? lo[1] : hi[1]) - r.src.y) * iy;
     if ((tmin > ymax) || (ymin > tmax)) return false;
     if (ymin > tmin) tmin = ymin;
     if (ymax < tmax) tmax = ymax;
-    double zmin = ((r.sz ? hi[2] : lo[2]) - r.src.z) * r.inv.z;
-    double zmax = ((r.sz ? lo[2] : hi[2]) - r.src.z) * r.inv.z;
+    const double iz = 1.0 / r.dir.z;
+    const bool sz = __double_as_longlong(r.dir.z) < 0;
+    double zmin = ((sz ? hi[2] : lo[2]) - r.src.z) * iz;
+    double zmax = ((sz ? lo[2] : hi[2]) - r.src.z) * iz;
     if ((tmin > zmax) || (zmin > tmax)) return false;
     ent = tmin; ext = tmax;
     return true;
@@ -60,28 +121,54 @@ PT_DEV bool box_intersect(const double lo[3], const double hi[3], const RayD &r,
 
 // KDNode::searchNode, util/kdtree.cpp:180-197: a hit only counts when the hit
 // point lies inside the node's own box (inclusive on all three axes).
-PT_DEV bool search_node(const DevScene &S, int node, const NodeA &na, const RayD &ray, HitD &h) {
+// The node's list, fetched through the scalar unit, for the lanes that are all in node `node0`.
+PT_DEV bool search_node_uniform(const DevScene &S, int node0, int first0, int count0, const RayD &ray, HitD &h) {
     bool found = false;
+    const double *tri = S.refTri + (size_t)first0 * 9;
+    for (int i = 0; i < count0; i++, tri += 9) {
+        double t, bu, bv;
+        if (tri_intersect(uload3(tri), uload3(tri + 3), uload3(tri + 6), ray, t, bu, bv) && t > 0 && t < h.tmin) {
+            D3 hit = dadd(ray.src, dscale(t, ray.dir));
+            const double *b = S.nodeBox + (size_t)node0 * 6;
+            const D3 lo = uload3(b), hi = uload3(b + 3);
+            if (!(hit.x >= lo.x && hit.y >= lo.y && hit.z >= lo.z && hit.x <= hi.x && hit.y <= hi.y && hit.z <= hi.z))
+                continue;
+            found = true;
+            h.tmin = t; h.u = bu; h.v = bv;
+            h.tri = ((PtUniformI)(uintptr_t)S.refId)[first0 + i];
+        }
+    }
+    return found;
+}
+
+// COHERENT: the rays of the wave are neighbours (sub-rays of a bundle, pixels of a tile, their mirror rays) and are in
+// one node, or a few, at any time: the distinct nodes are taken one after the other, each through the scalar unit
+// (one request per wave instead of one per lane, and no per-lane copy of the triangle in registers).  Otherwise
+// (incoherent rays) the scalar path is taken only when every lane is in the same node, and each lane loads for itself.
+template <bool COHERENT>
+PT_DEV bool search_node(const DevScene &S, int node, const NodeA &na, const RayD &ray, HitD &h) {
+    if (COHERENT) {
+        bool found = false, pending = true;
+        for (;;) {
+            if (pending) {
+                const int node0 = __builtin_amdgcn_readfirstlane(node);
+                if (node == node0) {
+                    const int first0 = __builtin_amdgcn_readfirstlane(na.first), count0 = __builtin_amdgcn_readfirstlane(na.count);
+                    found = search_node_uniform(S, node0, first0, count0, ray, h);
+                    pending = false;
+                }
+            }
+            if (!__any(pending)) break;
+        }
+        return found;
+    }
     const int node0 = __builtin_amdgcn_readfirstlane(node);
     if (__all(node == node0)) {
         // every active lane is in this node: its list comes through the scalar unit, once for the wave
         const int first0 = __builtin_amdgcn_readfirstlane(na.first), count0 = __builtin_amdgcn_readfirstlane(na.count);
-        const double *tri = S.refTri + (size_t)first0 * 9;
-        for (int i = 0; i < count0; i++, tri += 9) {
-            double t, bu, bv;
-            if (tri_intersect(uload3(tri), uload3(tri + 3), uload3(tri + 6), ray, t, bu, bv) && t > 0 && t < h.tmin) {
-                D3 hit = dadd(ray.src, dscale(t, ray.dir));
-                const double *b = S.nodeBox + (size_t)node0 * 6;
-                const D3 lo = uload3(b), hi = uload3(b + 3);
-                if (!(hit.x >= lo.x && hit.y >= lo.y && hit.z >= lo.z && hit.x <= hi.x && hit.y <= hi.y && hit.z <= hi.z))
-                    continue;
-                found = true;
-                h.tmin = t; h.u = bu; h.v = bv;
-                h.tri = ((PtUniformI)(uintptr_t)S.refId)[first0 + i];
-            }
-        }
-        return found;
+        return search_node_uniform(S, node0, first0, count0, ray, h);
     }
+    bool found = false;
     const double *tri = S.refTri + (size_t)na.first * 9;
     for (int i = 0; i < na.count; i++, tri += 9) {
         double t, bu, bv;
@@ -129,24 +216,19 @@ struct SearchNote {
 };
 
 // search(), util/kdtree.cpp:216-257.  h.tmin is the in/out bound.  NOTED: also fills *note.
-template <bool NOTED>
-PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, SearchNote *note) {
+template <bool NOTED, bool COHERENT>
+PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, SearchNote *note, StackD &st) {
     double ent, ext;
     if (NOTED) { note->far_max = -DBL_MAX; note->stack_min = DBL_MAX; }
     if (!box_intersect(S.root_lo, S.root_hi, ray, ent, ext)) return false;
-    int32_t sn[PT_STACK_MAX];
-    double se[PT_STACK_MAX], sx[PT_STACK_MAX];
-    int sp = 0;
-    sn[0] = 0; se[0] = ent; sx[0] = ext; sp = 1;
+    st.clear();
+    int curr = 0;                                   // the root entry is taken at once instead of pushed and popped
     bool found = false, at_leaf = false;
-    while (sp > 0) {
-        sp--;
-        int curr = sn[sp];
-        ent = se[sp]; ext = sx[sp];
-        if (ent >= h.tmin) break;
+    for (;;) {
+        if (ent >= h.tmin) break;                   // util/kdtree.cpp:229-231: ends the whole search
         NodeA na = fetch_node(S, curr);
         while (na.axis >= 0) {
-            if (na.count > 0) found |= search_node(S, curr, na, ray, h);
+            if (na.count > 0) found |= search_node<COHERENT>(S, curr, na, ray, h);
             double s = na.split;
             int a = na.axis;
             double da = dget(ray.dir, a), sa = dget(ray.src, a);
@@ -160,20 +242,21 @@ PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, SearchNote
                 if (NOTED && tmid > note->far_max) note->far_max = tmid;
                 curr = fr;
             } else {
-                if (tmid <= h.tmin && sp < PT_STACK_MAX) { sn[sp] = fr; se[sp] = tmid; sx[sp] = ext; sp++; }
+                if (tmid <= h.tmin) st.push(fr, tmid, ext);
                 curr = nr;
                 ext = tmid;
             }
             na = fetch_node(S, curr);
         }
-        if (na.count > 0 && search_node(S, curr, na, ray, h)) { at_leaf = true; break; }
+        if (na.count > 0 && search_node<COHERENT>(S, curr, na, ray, h)) { at_leaf = true; break; }
+        if (st.size() == 0) break;
+        st.pop(curr, ent, ext);
     }
-    if (NOTED)
-        for (int i = 0; i < sp; i++)
-            if (se[i] < note->stack_min) note->stack_min = se[i];
+    if (NOTED) note->stack_min = st.min_ent();
     return at_leaf || found;
 }
-PT_DEV bool search_ref(const DevScene &S, const RayD &ray, HitD &h) { return search_ref_t<false>(S, ray, h, nullptr); }
+template <bool COHERENT>
+PT_DEV bool search_ref(const DevScene &S, const RayD &ray, HitD &h, StackD &st) { return search_ref_t<false, COHERENT>(S, ray, h, nullptr, st); }
 
 // ---- shading ------------------------------------------------------------------
 
@@ -187,12 +270,18 @@ PT_DEV const uint8_t *texel(const DevScene &S, int tex, int px, int py) {
     return S.texels + S.tex_off[tex] + ((size_t)row * cols + col) * 3;
 }
 
-// PolygonMesh::surfaceProperties, util/polygonMesh.cpp:81-118.
-PT_DEV void surface_properties(const DevScene &S, int tri, double bu, double bv, D3 &nrm, D3 &txt, int &reft) {
+// PolygonMesh::surfaceProperties, util/polygonMesh.cpp:81-118, in two parts: the interpolated normal, which the light
+// loop needs, and the texture colour and mirror flag, which are only needed once the lights are done (nothing in
+// between depends on them, so fetching them later changes no value and keeps six registers free during the searches
+// of the light loop).
+PT_DEV D3 surface_normal(const DevScene &S, int tri, double bu, double bv) {
     const int32_t *N = S.tri_ni + (size_t)tri * 3;
     double w = 1.0 - bu - bv;
     D3 n0 = dload(S.norm + (size_t)N[0] * 3), n1 = dload(S.norm + (size_t)N[1] * 3), n2 = dload(S.norm + (size_t)N[2] * 3);
-    nrm = dunit(dadd(dadd(dscale(w, n0), dscale(bu, n1)), dscale(bv, n2)));
+    return dunit(dadd(dadd(dscale(w, n0), dscale(bu, n1)), dscale(bv, n2)));
+}
+PT_DEV void surface_texture(const DevScene &S, int tri, double bu, double bv, D3 &txt, int &reft) {
+    double w = 1.0 - bu - bv;
     int mn = S.tri_tm[tri];
     reft = S.tri_reft[tri];
     if (mn == -99999) { txt = d3(1, 1, 1); return; }
@@ -224,20 +313,25 @@ PT_DEV void surface_properties(const DevScene &S, int tri, double bu, double bv,
     }
 }
 
-// Light::illuminate, util/lighting.cpp:24-36.
-PT_DEV void illuminate(const PtLight &L, D3 hit, D3 &ldir, D3 &shade, double &dis) {
-    D3 pos = d3(L.pos[0], L.pos[1], L.pos[2]), color = d3(L.color[0], L.color[1], L.color[2]);
-    ldir = d3(0, 0, 0); shade = d3(0, 0, 0); dis = 0;
+// Light::illuminate, util/lighting.cpp:24-36, in two parts: direction + distance, and the radiance, which depends on the
+// light and the distance only.
+PT_DEV void illuminate_dir(const PtLight &L, D3 hit, D3 &ldir, double &dis) {
+    D3 pos = d3(L.pos[0], L.pos[1], L.pos[2]);
+    ldir = d3(0, 0, 0); dis = 0;
     if (L.type == 'd') {
         dis = (double)FLT_MAX;
         ldir = dunit(pos);
-        shade = dscale(L.mag, color);
     } else if (L.type == 'p') {
         ldir = dsub(pos, hit);
         dis = dlen(ldir);
         ldir = dunit(ldir);
-        shade = ddivs(dscale(L.mag, color), 4 * dis * 3.14159265358979323846);
     }
+}
+PT_DEV D3 illuminate_shade(const PtLight &L, double dis) {
+    D3 color = d3(L.color[0], L.color[1], L.color[2]);
+    if (L.type == 'd') return dscale(L.mag, color);
+    if (L.type == 'p') return ddivs(dscale(L.mag, color), 4 * dis * 3.14159265358979323846);
+    return d3(0, 0, 0);
 }
 
 // createCoordSystem, util/lighting.cpp:42-48.
@@ -254,62 +348,67 @@ struct GBufD { D3 clr, nrm, hit; };
 // Primary-hit record of the depth-0 call.
 struct PrimRec { int32_t found, tri; double t, u, v; };
 
-// castRay of main.cpp:41-78 (MODEL == PT_MODEL_MAIN) and mainOMP.cpp:37-78
-// (PT_MODEL_OMP).  depth: 0 primary, 1 MAIN's mirror bounce, -1 GI sample ray
-// or OMP's mirror bounce.  PRIMARY selects the depth-0 form, which evaluates its
-// one mirror bounce in line through the non-primary instantiation.
-template <int MODEL, bool PRIMARY>
-PT_DEV D3 cast_ray(const DevScene &S, const RayD &ray, int depth, GBufD *g, PrimRec *rec, RayCounts &rc) {
-    HitD h; h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
+// What castRay computes of a hit before its mirror bounce: search, surface properties, hit point, the light loop.
+struct CastHit { HitD h; D3 nrm, txt, hit, direct, alb; int reft; };
+
+// The first part of castRay, main.cpp:41-66 (MODEL == PT_MODEL_MAIN) / mainOMP.cpp:37-63 (PT_MODEL_OMP):
+// false on a miss (c.h then holds the search's record).
+template <int MODEL, bool COHERENT>
+PT_DEV bool cast_hit(const DevScene &S, const RayD &ray, StackD &st, RayCounts &rc, CastHit &c) {
+    HitD &h = c.h;
+    h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
     SearchNote note;
-    bool ok = MODEL == PT_MODEL_OMP ? search_ref_t<true>(S, ray, h, &note) : search_ref(S, ray, h);
-    if (rec) { rec->found = ok; rec->tri = h.tri; rec->t = h.tmin; rec->u = h.u; rec->v = h.v; }
-    if (!ok) {
-        if (depth == 0) {
-            if (g) g->hit = d3(-99999, -99999, -99999);
-            return d3(S.bg[0], S.bg[1], S.bg[2]);
-        }
-        return d3(0, 0, 0);
-    }
-    D3 nrm, txt; int reft;
-    surface_properties(S, h.tri, h.u, h.v, nrm, txt, reft);
-    D3 hit = dadd(dadd(ray.src, dscale(h.tmin, ray.dir)), dscale(0.0001, nrm));
-    D3 direct = d3(0, 0, 0), ref = d3(0, 0, 0);
+    bool ok = MODEL == PT_MODEL_OMP ? search_ref_t<true, COHERENT>(S, ray, h, &note, st) : search_ref<COHERENT>(S, ray, h, st);
+    if (!ok) return false;
+    c.nrm = surface_normal(S, h.tri, h.u, h.v);
+    c.hit = dadd(dadd(ray.src, dscale(h.tmin, ray.dir)), dscale(0.0001, c.nrm));
+    D3 direct = d3(0, 0, 0);
     // mainOMP.cpp:60: known to find nothing -- by the note of the first search, or because the last one found nothing
     // and so left h as it was, which makes the next one the same search
     bool retrace_clear = MODEL == PT_MODEL_OMP && !note.may_find_closer(h.tmin);
     for (int k = 0; k < S.n_light; k++) {
-        D3 ldir, shade; double dis;
-        illuminate(S.lights[k], hit, ldir, shade, dis);
+        // Light::illuminate (util/lighting.cpp:24-36) around the visibility search: direction and distance before it,
+        // the radiance after it (a function of the light and the distance only), so that it is not held in registers
+        // across the search.
+        D3 ldir; double dis;
+        illuminate_dir(S.lights[k], c.hit, ldir, dis);
         bool vis;
         if (MODEL == PT_MODEL_MAIN) {                        // main.cpp:62-63: a real shadow ray
-            RayD lray = make_ray(hit, ldir);
+            RayD lray = make_ray(c.hit, ldir);
             HitD sh; sh.tmin = dis; sh.tri = -1; sh.u = 0; sh.v = 0;
-            vis = !search_ref(S, lray, sh);
+            vis = !search_ref<COHERENT>(S, lray, sh, st);
             rc.n[RC_SHADOW]++;
         } else {                                             // mainOMP.cpp:60: re-traces `ray` bounded by its own hit
-            if (!retrace_clear) retrace_clear = !search_ref(S, ray, h);
+            if (!retrace_clear) retrace_clear = !search_ref<COHERENT>(S, ray, h, st);
             vis = retrace_clear;
             rc.n[RC_RETRACE]++;
         }
-        double cosv = ddot(ldir, nrm);
+        double cosv = ddot(ldir, c.nrm);
         double mx = (0.0 < cosv) ? cosv : 0.0;
-        direct = dadd(direct, dscale((vis ? 1.0 : 0.0) * mx, shade));
+        direct = dadd(direct, dscale((vis ? 1.0 : 0.0) * mx, illuminate_shade(S.lights[k], dis)));
     }
+    c.direct = direct;
+    surface_texture(S, h.tri, h.u, h.v, c.txt, c.reft);
     const double *ap = S.albedo + (size_t)S.tri_mesh[h.tri] * 3;
-    D3 alb = d3(ap[0], ap[1], ap[2]);
-    if constexpr (PRIMARY) {
-        if (g) { g->clr = dmul(txt, alb); g->hit = hit; g->nrm = nrm; }
-        if (reft) {
-            RayD rray = make_ray(hit, dreflect(ray.dir, nrm));
-            rc.n[RC_MIRROR]++;
-            ref = dadd(ref, cast_ray<MODEL, false>(S, rray, MODEL == PT_MODEL_MAIN ? 1 : -1, nullptr, nullptr, rc));
-        }
-    }
+    c.alb = d3(ap[0], ap[1], ap[2]);
+    return true;
+}
+
+// The value castRay returns for a hit whose mirror bounce (if any) returned `ref`: main.cpp:77 / mainOMP.cpp:74-76.
+template <int MODEL>
+PT_DEV D3 cast_value(const CastHit &c, int depth, D3 ref) {
     if (MODEL == PT_MODEL_OMP && depth == -1)
-        return ddivs(dmul(dmul(txt, alb), direct), 3.14159265358979323846);        // mainOMP.cpp:74-75
-    D3 a = ddivs(dmul(dmul(dscale(0.6, txt), alb), direct), 3.14159265358979323846); // main.cpp:77, mainOMP.cpp:76
+        return ddivs(dmul(dmul(c.txt, c.alb), c.direct), 3.14159265358979323846);        // mainOMP.cpp:74-75
+    D3 a = ddivs(dmul(dmul(dscale(0.6, c.txt), c.alb), c.direct), 3.14159265358979323846); // main.cpp:77, mainOMP.cpp:76
     return dadd(a, dscale(0.4, ref));
+}
+
+// castRay at depth != 0 (a GI sample ray, or the mirror bounce of a primary hit): no G-buffer, no further bounce.
+template <int MODEL, bool COHERENT>
+PT_DEV D3 cast_secondary(const DevScene &S, const RayD &ray, int depth, StackD &st, RayCounts &rc) {
+    CastHit c;
+    if (!cast_hit<MODEL, COHERENT>(S, ray, st, rc, c)) return d3(0, 0, 0);
+    return cast_value<MODEL>(c, depth, d3(0, 0, 0));
 }
 
 // Camera ray of main.cpp:119-121 / mainOMP.cpp:121-123; sa, ca = sin, cos of the

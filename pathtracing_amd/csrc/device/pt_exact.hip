@@ -1,7 +1,8 @@
-// Kernels of the fp64 reference-semantics path: one thread per pixel for the
-// primary pass (all of castRay at depth 0, sub-rays of a bundle in sequence so
-// that sums keep the reference's order), one thread per (pixel, sample) for
-// the GI pass, an ordered accumulation and the final quantisation.
+// Kernels of the fp64 reference-semantics path: one thread per sub-ray for the
+// primary pass (all of castRay at depth 0), one thread per (pixel, sample) for
+// the GI pass, an ordered accumulation and the final quantisation.  The kernels
+// that search the tree run as at most PT_EXACT_WAVES one-wave blocks that stride
+// over their work: each launched block owns a region of the stack overflow buffer.
 // Build with -ffp-contract=off.
 #include "pt_exact.h"
 #include "pt_frame.h"
@@ -35,40 +36,106 @@ PT_DEV void flush_counts(const RayCounts &rc, unsigned long long *counters) {
 // hundredth of a pixel, so they walk the tree together.  The sub-ray results are folded
 // into the frame buffers by k_primary_combine in the reference's order.
 template <int MODEL>
-__global__ void __launch_bounds__(64) k_primary_exact(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B) {
+__global__ void __launch_bounds__(64) k_primary_exact(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B, uint32_t nblocks) {
+    extern __shared__ double stack_lds[];
+    StackD st = make_stack(S, stack_lds);
     RayCounts rc;
 #pragma unroll
     for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t lin;
-    int sub = 4;
-    bool live = true;
-    if (V.rb) {
-        const uint32_t item = blockIdx.x * 63u + lane;
-        lin = item / 9u;
-        sub = (int)(item - lin * 9u);
-        live = lane < 63u;
-    } else {
-        lin = blockIdx.x * 64u + lane;
-    }
-    int i = 0, j = 0;
-    live = live && tile_pixel((int)lin, V.size, i, j) && own_row(V.part, V.n_parts, i);
-    if (live) {
+    // persistent waves: a launched block (it owns a region of the stack overflow buffer) draws work blocks from a counter
+    for (;;) {
+        uint32_t blk = 0;
+        if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_PRIMARY], 1ull);
+        blk = __builtin_amdgcn_readfirstlane(blk);
+        if (blk >= nblocks) break;
+        uint32_t lin;
+        int sub = 4;
+        bool live = true;
+        if (V.rb) {
+            const uint32_t item = blk * 63u + lane;
+            lin = item / 9u;
+            sub = (int)(item - lin * 9u);
+            live = lane < 63u;
+        } else {
+            lin = blk * 64u + lane;
+        }
+        int i = 0, j = 0;
+        live = live && tile_pixel((int)lin, V.size, i, j) && own_row(V.part, V.n_parts, i);
+        if (!live) continue;
         const size_t p = (size_t)i * V.size + j, slot = V.rb ? p * 9 + sub : p;
         // the offsets as the reference's loops produce them: -o, -o + o, (-o + o) + o  (main.cpp:116-117)
         const double o0 = -V.off, o1 = o0 + V.off, o2 = o1 + V.off;
         const int xi = sub % 3, yi = sub / 3;
         const double x = xi == 0 ? o0 : (xi == 1 ? o1 : o2), y = yi == 0 ? o0 : (yi == 1 ? o1 : o2);
         RayD ray = camera_ray(d3(V.eye[0], V.eye[1], V.eye[2]), V.zoom, V.sa, V.ca, V.size, i, j, x, y);
-        GBufD g;
-        g.clr = d3(0, 0, 0); g.nrm = d3(0, 0, 0); g.hit = d3(0, 0, 0);
-        PrimRec rec; rec.found = 0; rec.tri = -1; rec.t = -1; rec.u = 0; rec.v = 0;
         rc.n[RC_PRIMARY]++;
-        D3 paint = cast_ray<MODEL, true>(S, ray, 0, &g, &rec, rc);
+        // castRay at depth 0 (main.cpp:41-78 / mainOMP.cpp:37-78) up to its mirror bounce.  The G-buffer candidate and
+        // the hit record go to memory as soon as they are known.  A reflective hit leaves a = 0.6 txt albedo direct / pi
+        // in `paint` and its mirror ray's direction in `mdir`; k_mirror_exact adds the bounce.
+        CastHit c;
+        D3 paint;
+        int mirror = 0;
+        if (!cast_hit<MODEL, true>(S, ray, st, rc, c)) {
+            const D3 zero = d3(0, 0, 0);
+            dstore(B.g + 9 * slot, zero); dstore(B.g + 9 * slot + 3, zero); dstore(B.g + 9 * slot + 6, d3(-99999, -99999, -99999));
+            B.found[slot] = 0; B.tri[slot] = -1;
+            B.tuv[3 * slot] = -1.0; B.tuv[3 * slot + 1] = c.h.u; B.tuv[3 * slot + 2] = c.h.v;
+            paint = d3(S.bg[0], S.bg[1], S.bg[2]);
+        } else {
+            dstore(B.g + 9 * slot, dmul(c.txt, c.alb)); dstore(B.g + 9 * slot + 3, c.nrm); dstore(B.g + 9 * slot + 6, c.hit);
+            B.found[slot] = 1; B.tri[slot] = c.h.tri;
+            B.tuv[3 * slot] = c.h.tmin; B.tuv[3 * slot + 1] = c.h.u; B.tuv[3 * slot + 2] = c.h.v;
+            if (c.reft) {
+                mirror = 1;
+                paint = ddivs(dmul(dmul(dscale(0.6, c.txt), c.alb), c.direct), 3.14159265358979323846);
+                dstore(B.mdir + 3 * slot, dreflect(ray.dir, c.nrm));
+                rc.n[RC_MIRROR]++;
+            } else {
+                paint = cast_value<MODEL>(c, 0, d3(0, 0, 0));
+            }
+        }
+        B.mirror[slot] = mirror;
         dstore(B.paint + 3 * slot, paint);
-        dstore(B.g + 9 * slot, g.clr); dstore(B.g + 9 * slot + 3, g.nrm); dstore(B.g + 9 * slot + 6, g.hit);
-        B.found[slot] = rec.found; B.tri[slot] = rec.found ? rec.tri : -1;
-        B.tuv[3 * slot] = rec.found ? rec.t : -1.0; B.tuv[3 * slot + 1] = rec.u; B.tuv[3 * slot + 2] = rec.v;
+    }
+    flush_counts(rc, F.counters);
+}
+
+// The mirror bounce of the reflective primary hits (main.cpp:71-77 / mainOMP.cpp:68-76): same mapping of sub-rays to
+// lanes as k_primary_exact; paint = a + 0.4 * (0 + castRay(reflected ray)).
+template <int MODEL>
+__global__ void __launch_bounds__(64) k_mirror_exact(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B, uint32_t nblocks) {
+    extern __shared__ double stack_lds[];
+    StackD st = make_stack(S, stack_lds);
+    RayCounts rc;
+#pragma unroll
+    for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
+    const uint32_t lane = threadIdx.x & 63;
+    for (;;) {
+        uint32_t blk = 0;
+        if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_MIRROR], 1ull);
+        blk = __builtin_amdgcn_readfirstlane(blk);
+        if (blk >= nblocks) break;
+        uint32_t lin;
+        int sub = 0;
+        bool live = true;
+        if (V.rb) {
+            const uint32_t item = blk * 63u + lane;
+            lin = item / 9u;
+            sub = (int)(item - lin * 9u);
+            live = lane < 63u;
+        } else {
+            lin = blk * 64u + lane;
+        }
+        int i = 0, j = 0;
+        live = live && tile_pixel((int)lin, V.size, i, j) && own_row(V.part, V.n_parts, i);
+        if (!live) continue;
+        const size_t p = (size_t)i * V.size + j, slot = V.rb ? p * 9 + sub : p;
+        if (!B.mirror[slot]) continue;
+        const RayD rray = make_ray(dload(B.g + 9 * slot + 6), dload(B.mdir + 3 * slot));
+        D3 ref = d3(0, 0, 0);
+        ref = dadd(ref, cast_secondary<MODEL, true>(S, rray, MODEL == PT_MODEL_MAIN ? 1 : -1, st, rc));
+        dstore(B.paint + 3 * slot, dadd(dload(B.paint + 3 * slot), dscale(0.4, ref)));
     }
     flush_counts(rc, F.counters);
 }
@@ -114,15 +181,17 @@ __global__ void k_primary_combine(FrameBuffers F, SubBuffers B, int size, int rb
 // Thread t of the launch handles sample s0 + t / tile_threads and the pixel of
 // t % tile_threads; contrib holds r1 * castRay(iray, -1) in sample order.
 template <int MODEL>
-__global__ void __launch_bounds__(64) k_gi_exact(DevScene S, ViewParams V, FrameBuffers F, int s0, int tthreads) {
-    int lin = blockIdx.x * 64 + threadIdx.x;
-    int sl = lin / tthreads;
-    int i, j;
+__global__ void __launch_bounds__(64) k_gi_exact(DevScene S, ViewParams V, FrameBuffers F, int s0, int tthreads, uint32_t nblocks) {
+    extern __shared__ double stack_lds[];
+    StackD st = make_stack(S, stack_lds);
     RayCounts rc;
 #pragma unroll
     for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
-    bool live = tile_pixel(lin - sl * tthreads, V.size, i, j);
-    if (live) {
+    for (uint32_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        int lin = (int)(blk * 64u + threadIdx.x);
+        int sl = lin / tthreads;
+        int i, j;
+        if (!tile_pixel(lin - sl * tthreads, V.size, i, j)) continue;
         size_t P = (size_t)V.size * V.size, p = (size_t)i * V.size + j;
         D3 hit = dload(F.ghit + 3 * p);
         D3 out = d3(0, 0, 0);
@@ -136,7 +205,7 @@ __global__ void __launch_bounds__(64) k_gi_exact(DevScene S, ViewParams V, Frame
                           sm.x * Nb.z + sm.y * nrm.z + sm.z * Nt.z);
             RayD iray = make_ray(hit, world);
             rc.n[RC_GI]++;
-            out = dscale(r1, cast_ray<MODEL, false>(S, iray, -1, nullptr, nullptr, rc));
+            out = dscale(r1, cast_secondary<MODEL, false>(S, iray, -1, st, rc));
         }
         dstore(F.contrib + ((size_t)sl * P + p) * 3, out);
     }
@@ -171,24 +240,26 @@ __global__ void k_resolve(FrameBuffers F, int size, int gi, int nsamples) {
 
 // search() on caller-supplied rays.  With `research` the outputs are those of a second search of the same ray bounded
 // by the first one's hit (mainOMP.cpp:60), done the way cast_ray does it: only when the first search's note asks for it.
-__global__ void k_trace_exact(DevScene S, size_t n, const double *src, const double *dir, const double *tmin_in,
-                              int32_t *found, int32_t *tri, double *t, double *u, double *v, int research) {
-    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    RayD ray = make_ray(dload(src + 3 * k), dload(dir + 3 * k));
-    HitD h; h.tmin = tmin_in[k]; h.tri = -1; h.u = 0; h.v = 0;
-    bool ok;
-    if (research) {
-        SearchNote note;
-        ok = search_ref_t<true>(S, ray, h, &note);
-        if (ok) {
-            h.tri = -1; h.u = 0; h.v = 0;                 // the bound stays: the first hit's distance
-            ok = note.may_find_closer(h.tmin) && search_ref(S, ray, h);
+__global__ void __launch_bounds__(64) k_trace_exact(DevScene S, size_t n, const double *src, const double *dir, const double *tmin_in,
+                                                    int32_t *found, int32_t *tri, double *t, double *u, double *v, int research) {
+    extern __shared__ double stack_lds[];
+    StackD st = make_stack(S, stack_lds);
+    for (size_t k = (size_t)blockIdx.x * 64 + threadIdx.x; k < n; k += (size_t)gridDim.x * 64) {
+        RayD ray = make_ray(dload(src + 3 * k), dload(dir + 3 * k));
+        HitD h; h.tmin = tmin_in[k]; h.tri = -1; h.u = 0; h.v = 0;
+        bool ok;
+        if (research) {
+            SearchNote note;
+            ok = search_ref_t<true, false>(S, ray, h, &note, st);
+            if (ok) {
+                h.tri = -1; h.u = 0; h.v = 0;                 // the bound stays: the first hit's distance
+                ok = note.may_find_closer(h.tmin) && search_ref<false>(S, ray, h, st);
+            }
+        } else {
+            ok = search_ref<false>(S, ray, h, st);
         }
-    } else {
-        ok = search_ref(S, ray, h);
+        found[k] = ok; tri[k] = h.tri; t[k] = h.tmin; u[k] = h.u; v[k] = h.v;
     }
-    found[k] = ok; tri[k] = h.tri; t[k] = h.tmin; u[k] = h.u; v[k] = h.v;
 }
 
 __global__ void k_camera_rays(ViewParams V, double x, double y, double *dir) {
@@ -210,15 +281,34 @@ __global__ void k_hemisphere(uint32_t seed, uint32_t view, uint32_t pixel, int n
 // ---- host-side launchers ----------------------------------------------------------
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? PT_OK : PT_ERR_HIP)
 
+// Blocks to launch a striding search kernel with: as many one-wave blocks as the device holds at once (so that no
+// block waits for another to finish: a second round of blocks would run at a fraction of the occupancy), at most
+// PT_EXACT_WAVES (the stack overflow regions) and at most the work.
+template <typename K>
+static unsigned resident_waves(K kernel, size_t work_blocks) {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, PT_RING64_LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    size_t w = (size_t)per_cu * (size_t)cus;
+    if (w > PT_EXACT_WAVES) w = PT_EXACT_WAVES;
+    if (w > work_blocks) w = work_blocks;
+    return (unsigned)(w < 1 ? 1 : w);
+}
+
 int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const SubBuffers &B, hipStream_t s) {
     const size_t P = (size_t)V.size * V.size;
     const unsigned cblocks = (unsigned)((P + 255) / 256);
     const unsigned blocks = V.rb ? (unsigned)(((size_t)tile_threads(V.size) * 9 + 62) / 63) : (unsigned)(tile_threads(V.size) / 64);
     if (V.model == PT_MODEL_MAIN) {
-        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_MAIN>, dim3(blocks), dim3(64), 0, s, S, V, F, B);
+        static const unsigned wp = resident_waves(k_primary_exact<PT_MODEL_MAIN>, PT_EXACT_WAVES), wm = resident_waves(k_mirror_exact<PT_MODEL_MAIN>, PT_EXACT_WAVES);
+        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_MAIN>, dim3(blocks < wp ? blocks : wp), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
+        if (S.any_mirror) hipLaunchKernelGGL(k_mirror_exact<PT_MODEL_MAIN>, dim3(blocks < wm ? blocks : wm), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         hipLaunchKernelGGL(k_primary_combine<PT_MODEL_MAIN>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb, V.part, V.n_parts);
     } else {
-        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_OMP>, dim3(blocks), dim3(64), 0, s, S, V, F, B);
+        static const unsigned wp = resident_waves(k_primary_exact<PT_MODEL_OMP>, PT_EXACT_WAVES), wm = resident_waves(k_mirror_exact<PT_MODEL_OMP>, PT_EXACT_WAVES);
+        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_OMP>, dim3(blocks < wp ? blocks : wp), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
+        if (S.any_mirror) hipLaunchKernelGGL(k_mirror_exact<PT_MODEL_OMP>, dim3(blocks < wm ? blocks : wm), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         hipLaunchKernelGGL(k_primary_combine<PT_MODEL_OMP>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb, V.part, V.n_parts);
     }
     return LAUNCH_OK();
@@ -227,10 +317,12 @@ int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F,
 int exact_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, int s0, int nb, hipStream_t s) {
     int tthreads = tile_threads(V.size);
     unsigned blocks = (unsigned)(((size_t)tthreads * nb) / 64);
+    static const unsigned w0 = resident_waves(k_gi_exact<PT_MODEL_MAIN>, PT_EXACT_WAVES), w1 = resident_waves(k_gi_exact<PT_MODEL_OMP>, PT_EXACT_WAVES);
+    const unsigned wr = V.model == PT_MODEL_MAIN ? w0 : w1, waves = blocks < wr ? blocks : wr;
     if (V.model == PT_MODEL_MAIN)
-        hipLaunchKernelGGL(k_gi_exact<PT_MODEL_MAIN>, dim3(blocks), dim3(64), 0, s, S, V, F, s0, tthreads);
+        hipLaunchKernelGGL(k_gi_exact<PT_MODEL_MAIN>, dim3(waves), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, s0, tthreads, blocks);
     else
-        hipLaunchKernelGGL(k_gi_exact<PT_MODEL_OMP>, dim3(blocks), dim3(64), 0, s, S, V, F, s0, tthreads);
+        hipLaunchKernelGGL(k_gi_exact<PT_MODEL_OMP>, dim3(waves), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, s0, tthreads, blocks);
     return LAUNCH_OK();
 }
 
@@ -248,7 +340,10 @@ int resolve_frame(const FrameBuffers &F, int size, int gi, int nsamples, hipStre
 
 int exact_trace(const DevScene &S, size_t n, const double *src, const double *dir, const double *tmin_in,
                 int32_t *found, int32_t *tri, double *t, double *u, double *v, int research, hipStream_t s) {
-    hipLaunchKernelGGL(k_trace_exact, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, S, n, src, dir, tmin_in, found, tri, t, u, v, research);
+    const size_t blocks = (n + 63) / 64;
+    static const unsigned wr = resident_waves(k_trace_exact, PT_EXACT_WAVES);
+    hipLaunchKernelGGL(k_trace_exact, dim3((unsigned)(blocks < wr ? blocks : wr)), dim3(64), PT_RING64_LDS_BYTES, s, S, n,
+                       src, dir, tmin_in, found, tri, t, u, v, research);
     return LAUNCH_OK();
 }
 

@@ -44,6 +44,8 @@ struct SubBuffers {
     double *g;                 // 9: mclr, mnrm, mhit candidate
     int32_t *found, *tri;
     double *tuv;               // 3: t, u, v
+    int32_t *mirror;           // the hit is reflective: `paint` holds the hit's own term until the bounce is added
+    double *mdir;              // 3: direction of the mirror ray (its origin is the hit point in `g`)
 };
 
 // Queues and slots of the fp32 GI wavefront path (pt_fast.hip).
@@ -68,6 +70,7 @@ struct FastBuffers {
 static inline int tile_threads(int size) { int t = (size + 7) >> 3; return t * t * 64; }
 
 // ---- pt_exact.hip ----
+#define PT_EXACT_WAVES 4096u       // one-wave blocks of a launch of an fp64 search kernel (each owns a stack overflow region)
 int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const SubBuffers &B, hipStream_t s);
 int exact_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, int s0, int nb, hipStream_t s);
 int gi_accumulate(const FrameBuffers &F, int size, int nb, int first_batch, hipStream_t s);

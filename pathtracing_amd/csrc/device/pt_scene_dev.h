@@ -40,6 +40,8 @@ struct DevScene {
     const double *nodeBox;     // 6 per node: lo, hi
     const double *refTri;      // 9 per ref: v0, v1 - v0, v2 - v0
     const int32_t *refId;      // triangle index per ref
+    double *ovf64;             // overflow of the fp64 search's stack: [block][entry][field][lane], ovf64_entries entries of 3 doubles
+    uint32_t ovf64_entries;    //   per lane for each of the PT_EXACT_WAVES blocks the fp64 kernels are launched with
     // ---- fp32 fast path ----
     const NodeF *nodeF;
     const float4 *refTriF;     // 3 float4 per ref: (v0, id bits), (e2.x, e1.x, e2.y, e1.y), (e2.z, e1.z, 0, 0)
@@ -60,8 +62,10 @@ struct DevScene {
     const PtLight *lights;
     const float4 *lightsF;     // fp32 lights, two float4 each: (position, type), (mag * colour, 0)
     int32_t n_light, n_node, n_ref, n_tri;
+    int32_t any_mirror;        // some triangle is reflective (the mirror pass of the primary kernel is skipped otherwise)
     double bg[3];
     double root_lo[3], root_hi[3];
 };
 
-enum { RC_PRIMARY = 0, RC_SHADOW = 1, RC_MIRROR = 2, RC_GI = 3, RC_RETRACE = 4, RC_N = 8 };
+// ray counters of a view, then the work counters the persistent primary / mirror kernels draw their blocks from
+enum { RC_PRIMARY = 0, RC_SHADOW = 1, RC_MIRROR = 2, RC_GI = 3, RC_RETRACE = 4, RC_WORK_PRIMARY = 5, RC_WORK_MIRROR = 6, RC_N = 8 };

@@ -30,16 +30,13 @@ PT_DEV double dget(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 PT_DEV D3 dload(const double *p) { return d3(p[0], p[1], p[2]); }
 PT_DEV void dstore(double *p, D3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
 
-// Ray with reciprocal direction and sign bits, util/polygonMesh.cpp:10-20.
-struct RayD { D3 src, dir, inv; int sx, sy, sz; };
+// Ray, util/polygonMesh.cpp:10-20.  Its reciprocal direction and sign bits are read by the box test only, which
+// forms them itself (pt_exact.h).
+struct RayD { D3 src, dir; };
 
 PT_DEV RayD make_ray(D3 src, D3 dir) {
     RayD r;
     r.src = src; r.dir = dir;
-    r.inv = d3(1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z);
-    r.sx = (int)((unsigned long long)__double_as_longlong(dir.x) >> 63);
-    r.sy = (int)((unsigned long long)__double_as_longlong(dir.y) >> 63);
-    r.sz = (int)((unsigned long long)__double_as_longlong(dir.z) >> 63);
     return r;
 }
 
