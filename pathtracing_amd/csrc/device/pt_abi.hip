@@ -264,6 +264,8 @@ int upload(const PtSceneDesc *d, PtScene **out) {
         // overflow stack of the fp32 traversal: one column of (tree depth + 2) entries per lane of every
         // wave the trace kernels are launched with
         S.ovf_depth = (uint32_t)sc->refine.max_depth + 2u;
+        // PT_TUNE_OVF_DEPTH: a smaller stack than the tree needs, for the test of the limit report
+        if (const char *e = getenv("PT_TUNE_OVF_DEPTH")) { int k = atoi(e); if (k >= 1 && (uint32_t)k < S.ovf_depth) S.ovf_depth = (uint32_t)k; }
         S.ovf_waves = PT_TRACE_WAVES;
         void *p = nullptr;
         size_t bytes = (size_t)S.ovf_waves * S.ovf_depth * 64 * sizeof(uint2);
@@ -281,6 +283,13 @@ int upload(const PtSceneDesc *d, PtScene **out) {
         sc->owned.push_back(p);
         sc->dev_bytes += bytes;
         S.ovf64 = (double *)p;
+    }
+    {
+        void *p = nullptr;
+        if (hipMalloc(&p, sizeof(unsigned long long)) != hipSuccess) return bail(fail(PT_ERR_OOM, "out of device memory"));
+        sc->owned.push_back(p);
+        S.err = (unsigned long long *)p;
+        HIPCHK(hipMemset(p, 0, sizeof(unsigned long long)));
     }
     UP(dev_copy(sc, tgeo.data(), tgeo.size(), &S.triGeo));
     UP(dev_copy(sc, tng.data(), tng.size(), &S.triNgF));
@@ -345,6 +354,24 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     if (e != hipSuccess) return bail(fail(PT_ERR_HIP, std::string("stream/event creation: ") + hipGetErrorString(e)));
     *out = holder.release();
     return PT_OK;
+}
+
+// The limit word of the scene after the kernels of a call have finished (the caller has synchronised the scene's
+// stream): zero, or the call fails.  The word is cleared for the next call.
+std::string limit_message(const char *what, unsigned long long e) {
+    std::string msg = std::string(what) + ": a kernel limit was exceeded, the result is not valid (";
+    if (e & PT_LIMIT_F32_STACK) msg += "fp32 traversal overflow stack full; ";
+    if (e & PT_LIMIT_F32_STEPS) msg += "fp32 traversal ended a ray at the bound on node steps; ";
+    if (e & PT_LIMIT_F64_STACK) msg += "fp64 search overflow stack full; ";
+    return msg + "flags " + std::to_string(e) + ")";
+}
+int check_limits(PtScene *sc, const char *what) {
+    unsigned long long e = 0;
+    HIPCHK(hipMemcpyAsync(&e, sc->S.err, sizeof e, hipMemcpyDeviceToHost, sc->stream));
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    if (!e) return PT_OK;
+    HIPCHK(hipMemsetAsync(sc->S.err, 0, sizeof e, sc->stream));
+    return fail(PT_ERR_LIMIT, limit_message(what, e));
 }
 
 int ensure_workspace(PtScene *sc, int size, int batch, bool fast, int nsub) {
@@ -436,20 +463,23 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     V.part = o->n_parts > 1 ? o->part : 0; V.n_parts = o->n_parts > 1 ? o->n_parts : 1;
     hipStream_t s = sc->stream;
     HIPCHK(hipMemsetAsync(F.counters, 0, RC_N * sizeof(unsigned long long), s));
-    if (exact_primary(sc->S, V, F, sc->ws.B, s)) return fail(PT_ERR_HIP, "primary pass launch failed");
+    // the kernels of a view report tripped limits in the last word of the view's counter block, read with the counters
+    DevScene S = sc->S;
+    S.err = F.counters + RC_LIMITS;
+    if (exact_primary(S, V, F, sc->ws.B, s)) return fail(PT_ERR_HIP, "primary pass launch failed");
     *gi_ms = 0; *gi_launches = 0;
     uint64_t fast_rays = 0, fast_shadow = 0, fast_work[2] = {0, 0};
     const bool count_work = fast && (o->flags & PT_FLAG_COUNT_WORK);
     if (o->gi) {
         if (fast) {
-            rc = fast_gi(sc->S, V, F, sc->ws.Q, N, batch, s, sc->stream_gen, sc->pass_events, gi_ms, gi_launches, &fast_rays, &fast_shadow,
+            rc = fast_gi(S, V, F, sc->ws.Q, N, batch, s, sc->stream_gen, sc->pass_events, gi_ms, gi_launches, &fast_rays, &fast_shadow,
                          count_work ? fast_work : nullptr);
             if (rc) return fail(rc, std::string("GI wavefront pass failed: ") + hipGetErrorString(hipGetLastError()));
         } else {
             for (int s0 = 0; s0 < N; s0 += batch) {
                 int nb = N - s0 < batch ? N - s0 : batch;
                 HIPCHK(hipEventRecord(sc->ev0, s));
-                if (exact_gi(sc->S, V, F, s0, nb, s)) return fail(PT_ERR_HIP, "GI pass launch failed");
+                if (exact_gi(S, V, F, s0, nb, s)) return fail(PT_ERR_HIP, "GI pass launch failed");
                 HIPCHK(hipEventRecord(sc->ev1, s));
                 if (gi_accumulate(F, size, nb, s0 == 0, s)) return fail(PT_ERR_HIP, "GI accumulation launch failed");
                 HIPCHK(hipEventSynchronize(sc->ev1));
@@ -460,10 +490,11 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
         }
     }
     if (resolve_frame(F, size, o->gi ? 1 : 0, N, s)) return fail(PT_ERR_HIP, "resolve launch failed");
+    unsigned long long c[RC_N];
+    HIPCHK(hipMemcpyAsync(c, F.counters, sizeof c, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (c[RC_LIMITS]) return fail(PT_ERR_LIMIT, limit_message("render", c[RC_LIMITS]));
     if (st) {
-        unsigned long long c[RC_N];
-        HIPCHK(hipMemcpyAsync(c, F.counters, sizeof c, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
         st->primary += c[RC_PRIMARY]; st->shadow += c[RC_SHADOW]; st->mirror += c[RC_MIRROR];
         st->gi += c[RC_GI] + fast_rays; st->shadow += fast_shadow; st->omp_retrace += c[RC_RETRACE];
         st->ms_gi_trace += *gi_ms; st->gi_trace_launches += *gi_launches;
@@ -534,14 +565,29 @@ int pt_scene_free(PtScene *sc) {
 
 // ---- blob form: header, then the arrays of PtSceneDesc back to back (8-byte aligned) ----
 struct BlobHeader {
-    char magic[8];            // "PTBLOB01"
+    char magic[8];            // "PTBLOB02"
     uint32_t counts[9];       // n_mesh .. n_ref in PtSceneDesc order
     uint32_t reserved;
     double background[3];
     uint64_t total_bytes;
+    uint64_t checksum;        // blob_checksum() of the whole blob with this field zero
 };
 
 static size_t pad8(size_t n) { return (n + 7) & ~(size_t)7; }
+
+// A blob travels between processes and machines (broadcast, files): any damage on the way must be refused, also where
+// it would still pass the structural checks (a flipped bit in a coordinate).  64-bit multiply-rotate hash over the
+// blob's 8-byte words; the sections are padded to 8 bytes, so the blob is a whole number of words.
+static uint64_t blob_checksum(const uint8_t *p, size_t bytes) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ bytes;
+    for (size_t o = 0; o + 8 <= bytes; o += 8) {
+        uint64_t w;
+        std::memcpy(&w, p + o, 8);
+        h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+        h = (h << 27) | (h >> 37);
+    }
+    return h ^ (h >> 33);
+}
 
 static size_t blob_bytes(const PtSceneDesc *d) {
     size_t n = sizeof(BlobHeader);
@@ -570,7 +616,7 @@ int pt_scene_blob_write(const PtSceneDesc *d, void *blob, size_t bytes) { return
     uint8_t *p = (uint8_t *)blob;
     std::memset(p, 0, blob_bytes(d));
     BlobHeader h{};
-    std::memcpy(h.magic, "PTBLOB01", 8);
+    std::memcpy(h.magic, "PTBLOB02", 8);
     const uint32_t c[9] = {d->n_mesh, d->n_vert, d->n_norm, d->n_uv, d->n_tri, d->n_tex, d->n_light, d->n_node, d->n_ref};
     std::memcpy(h.counts, c, sizeof c);
     for (int k = 0; k < 3; k++) h.background[k] = d->background[k];
@@ -590,6 +636,8 @@ int pt_scene_blob_write(const PtSceneDesc *d, void *blob, size_t bytes) { return
     put(d->lights, (size_t)d->n_light * sizeof(PtLight));
     put(d->nodes, (size_t)d->n_node * sizeof(PtKdNode));
     put(d->refs, (size_t)d->n_ref * 4);
+    h.checksum = blob_checksum(p, (size_t)h.total_bytes);      // the header in place still has a zero checksum
+    std::memcpy(p, &h, sizeof h);
     return PT_OK;
 }); }
 
@@ -598,7 +646,29 @@ int pt_scene_upload_blob(const void *blob, size_t bytes, PtScene **out) { return
     const uint8_t *p = (const uint8_t *)blob;
     BlobHeader h;
     std::memcpy(&h, p, sizeof h);
-    if (std::memcmp(h.magic, "PTBLOB01", 8) != 0 || h.total_bytes > bytes) return fail(PT_ERR_INVALID, "not a scene blob, or truncated");
+    if (std::memcmp(h.magic, "PTBLOB02", 8) != 0 || h.total_bytes > bytes || h.total_bytes < sizeof h || (h.total_bytes & 7))
+        return fail(PT_ERR_INVALID, "not a scene blob, or truncated");
+    {
+        // checksum of the blob with the checksum field zero, computed without copying the blob: header apart
+        BlobHeader z = h;
+        z.checksum = 0;
+        std::vector<uint8_t> head(sizeof z);
+        std::memcpy(head.data(), &z, sizeof z);
+        // hash = fold over words; fold the zeroed header first, then the rest, exactly as blob_checksum does over the whole
+        uint64_t acc = 0x9E3779B97F4A7C15ull ^ (size_t)h.total_bytes;
+        auto fold = [&](const uint8_t *q, size_t n) {
+            for (size_t o = 0; o + 8 <= n; o += 8) {
+                uint64_t w;
+                std::memcpy(&w, q + o, 8);
+                acc = (acc ^ w) * 0xFF51AFD7ED558CCDull;
+                acc = (acc << 27) | (acc >> 37);
+            }
+        };
+        static_assert(sizeof(BlobHeader) % 8 == 0, "the header is a whole number of checksum words");
+        fold(head.data(), sizeof z);
+        fold(p + sizeof z, (size_t)h.total_bytes - sizeof z);
+        if ((acc ^ (acc >> 33)) != h.checksum) return fail(PT_ERR_INVALID, "scene blob is damaged (checksum mismatch)");
+    }
     PtSceneDesc d{};
     d.struct_size = sizeof d;
     d.n_mesh = h.counts[0]; d.n_vert = h.counts[1]; d.n_norm = h.counts[2]; d.n_uv = h.counts[3]; d.n_tri = h.counts[4];
@@ -735,6 +805,7 @@ int pt_trace(PtScene *sc, size_t n, const double *src, const double *dir, const 
     TR(hipStreamSynchronize(s));
 #undef TR
     cleanup();
+    if (int lrc = check_limits(sc, "pt_trace")) return lrc;
     for (size_t k = 0; k < n; k++) {
         int32_t g = tri[k];
         mesh[k] = g < 0 ? -1 : sc->tri_mesh[g];
@@ -757,7 +828,7 @@ int pt_trace_device(PtScene *sc, size_t n, const double *d_src, const double *d_
     int rc = fast_trace_static(sc->S, g_device, n, d_src, d_dir, d_tmin_in, d_found, d_mesh, d_tri, d_t, d_u, d_v, sc->stream);
     if (rc == PT_ERR_HIP) return fail(rc, std::string("pt_trace_device: ") + hipGetErrorString(hipGetLastError()));
     if (rc) return fail(rc, "pt_trace_device: no scratch address for this device (pt_init), or a size limit");
-    return PT_OK;
+    return check_limits(sc, "pt_trace_device");
 }
 
 int pt_camera_rays(const PtCamera *cam, int size, double x, double y, double *dir_out) {

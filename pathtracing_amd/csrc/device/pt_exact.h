@@ -21,14 +21,20 @@ struct StackD {
     double *ent, *ext;        // LDS, this lane's column; entry k at [k * 64]
     uint32_t *node;
     double *ovf;              // device memory, this lane's column; field f of entry e at [(3 * e + f) * 64]
-    uint32_t top, cnt, novf;
+    uint32_t top, cnt, novf, cap;
+    unsigned long long *err;
     PT_DEV void clear() { top = 0; cnt = 0; novf = 0; }
     PT_DEV uint32_t size() const { return cnt + novf; }
     PT_DEV void push(int n, double e, double x) {
         if (cnt == PT_RING64) {                      // full: `top` is also the oldest entry's slot
-            double *o = ovf + (size_t)novf * 192;
-            o[0] = __longlong_as_double((long long)node[top * 64]); o[64] = ent[top * 64]; o[128] = ext[top * 64];
-            novf++; cnt--;
+            if (novf < cap) {
+                double *o = ovf + (size_t)novf * 192;
+                o[0] = __longlong_as_double((long long)node[top * 64]); o[64] = ent[top * 64]; o[128] = ext[top * 64];
+                novf++;
+            } else {
+                atomicOr(err, (unsigned long long)PT_LIMIT_F64_STACK);     // cannot happen for a tree of the uploaded depth
+            }
+            cnt--;
         }
         node[top * 64] = (uint32_t)n; ent[top * 64] = e; ext[top * 64] = x;
         top = (top + 1u) & (PT_RING64 - 1u);
@@ -60,6 +66,7 @@ PT_DEV StackD make_stack(const DevScene &S, double *lds) {
     st.ent = lds + lane; st.ext = lds + PT_RING64 * 64 + lane;
     st.node = (uint32_t *)(lds + 2 * PT_RING64 * 64) + lane;
     st.ovf = S.ovf64 + (size_t)blockIdx.x * S.ovf64_entries * 192 + lane;
+    st.cap = S.ovf64_entries; st.err = S.err;
     st.clear();
     return st;
 }

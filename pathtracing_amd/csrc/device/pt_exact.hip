@@ -24,7 +24,7 @@ PT_DEV uint32_t wave_sum(uint32_t v) {
 }
 PT_DEV void flush_counts(const RayCounts &rc, unsigned long long *counters) {
 #pragma unroll
-    for (int k = 0; k < RC_N; k++) {
+    for (int k = 0; k < RC_WORK_PRIMARY; k++) {          // the ray classes; the words after them are not ray counts
         uint32_t s = wave_sum(rc.n[k]);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(&counters[k], (unsigned long long)s);
     }

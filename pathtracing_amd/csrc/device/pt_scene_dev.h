@@ -62,10 +62,15 @@ struct DevScene {
     const PtLight *lights;
     const float4 *lightsF;     // fp32 lights, two float4 each: (position, type), (mag * colour, 0)
     int32_t n_light, n_node, n_ref, n_tri;
+    // Limits a kernel ran into: bit 0 the fp32 traversal's overflow stack was full (an entry was lost), bit 1 a ray was
+    // ended by the bound on node steps, bit 2 the fp64 search's overflow region was full.  The host reads the word after
+    // every call and reports PT_ERR_LIMIT; a result produced under a tripped limit is never handed out as good.
+    unsigned long long *err;
     int32_t any_mirror;        // some triangle is reflective (the mirror pass of the primary kernel is skipped otherwise)
     double bg[3];
     double root_lo[3], root_hi[3];
 };
 
 // ray counters of a view, then the work counters the persistent primary / mirror kernels draw their blocks from
-enum { RC_PRIMARY = 0, RC_SHADOW = 1, RC_MIRROR = 2, RC_GI = 3, RC_RETRACE = 4, RC_WORK_PRIMARY = 5, RC_WORK_MIRROR = 6, RC_N = 8 };
+enum { PT_LIMIT_F32_STACK = 1, PT_LIMIT_F32_STEPS = 2, PT_LIMIT_F64_STACK = 4 };
+enum { RC_PRIMARY = 0, RC_SHADOW = 1, RC_MIRROR = 2, RC_GI = 3, RC_RETRACE = 4, RC_WORK_PRIMARY = 5, RC_WORK_MIRROR = 6, RC_LIMITS = 7, RC_N = 8 };

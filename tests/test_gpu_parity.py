@@ -331,22 +331,32 @@ def test_errors(gpu_scenes, host_scenes):
         sc.render([0, 0, 0], 0.0, 1.0, size=100000)
     with pytest.raises(device.DeviceError):
         device.DeviceScene(blob=np.zeros(64, np.uint8))
-    # a scene blob that was cut short, and one whose tree links or indices were damaged, are refused before
+    # a scene blob that was cut short, and one damaged anywhere (the blob carries a checksum), are refused before
     # anything reaches the kernels (which index the pools unchecked)
     blob = device.scene_blob(host_scenes("cbox").desc())
     with pytest.raises(device.DeviceError):
         device.DeviceScene(blob=blob[: len(blob) // 2])
     rng = np.random.default_rng(5)
-    refused = 0
-    for _ in range(8):
+    for trial in range(8):
         bad = blob.copy()
-        at = rng.integers(len(bad) // 2, len(bad) - 4, 64)         # the second half holds kd nodes and references
-        bad[at] = 0xFF
-        try:
+        if trial < 6:
+            at = rng.integers(len(bad) // 2, len(bad) - 4, 64)         # the second half holds kd nodes and references
+            bad[at] = 0xFF
+        elif trial == 6:
+            bad[int(rng.integers(64, len(bad)))] ^= 0x01              # a single flipped bit
+        else:
+            bad[40] ^= 0x10                                           # in the header's counts
+        with pytest.raises(device.DeviceError):
             device.DeviceScene(blob=bad).close()
-        except device.DeviceError:
-            refused += 1
-    assert refused >= 6
+    # structural damage under a valid checksum is still caught by the scene checks: a description whose kd links are wrong
+    d = host_scenes("cbox").desc()
+    keep = d.nodes[0].left
+    d.nodes[0].left = d.n_node + 5
+    try:
+        with pytest.raises(device.DeviceError, match="tree"):
+            device.DeviceScene(d)
+    finally:
+        d.nodes[0].left = keep
 
 
 @pytest.fixture(scope="module")
@@ -398,6 +408,28 @@ def test_ring_overflow_to_device_stack(atrium_small, monkeypatch):
     small = ds.trace(src, d, tmin, mode=1)
     for k in ("found", "mesh", "tri", "t", "u", "v"):
         assert np.array_equal(ref[k], small[k]), k
+
+
+def test_a_full_overflow_stack_is_an_error_not_a_wrong_answer(host_scenes, monkeypatch):
+    """With a 2-entry ring and an overflow stack cut to one entry (a test knob; the real one is sized for the tree's
+    depth) entries get lost: the call must fail with PT_ERR_LIMIT instead of returning hits it cannot vouch for, and
+    the next call on a properly sized scene works."""
+    hs = host_scenes("car")
+    src, d = random_rays(20000, 5, [-500, 0, -500, 500, 1000, 500])
+    tmin = np.full(len(src), device.FLT_MAX)
+    monkeypatch.setenv("PT_TUNE_OVF_DEPTH", "1")
+    monkeypatch.setenv("PT_TUNE_SLOTS", "2")
+    small = device.DeviceScene(hs.desc())
+    with pytest.raises(device.DeviceError, match="overflow stack full"):
+        small.trace(src, d, tmin, mode=1)
+    cam = hs.camera()
+    with pytest.raises(device.DeviceError, match="limit"):
+        small.render(cam["eye"], cam["angle"], cam["zoom"], gi=True, spp=4, size=64, gi_precision=device.GI_F32_FAST)
+    small.close()
+    monkeypatch.delenv("PT_TUNE_OVF_DEPTH")
+    ok = device.DeviceScene(hs.desc())
+    assert ok.trace(src, d, tmin, mode=1)["found"].sum() > 0
+    ok.close()
 
 
 def test_fast_tree_variants_agree(host_scenes, monkeypatch):
