@@ -499,6 +499,59 @@ def test_full_size_atrium_properties():
         ds.close()
 
 
+@pytest.mark.parametrize("triangles,what", [(340265, "room-class stand-in"), (262267, "atrium")])
+def test_full_size_ray_bundles_properties(triangles, what):
+    """-gi -rb at full size (512 x 512, mainOMP model) on the stand-ins for the two meshes the reference does not ship:
+    the room-class scene (340 265 triangles, the configuration `room -gi -rb`) and the atrium (262 267, the views of
+    the multi-view job).  The oracle is too slow to be the checker here, so size-independent properties: the census
+    (nine sub-rays per pixel, one GI ray per sample and hit pixel of the centre ray, no shadow rays in this model),
+    frames that do not depend on the number of GI passes, on what was rendered before, or on whether a view is
+    rendered alone or inside pt_render_views, a -rb frame that differs from the plain one only by anti-aliasing, and
+    the fp32 GI path within a byte in a thousand of the fp64 one."""
+    from pathtracing_amd import host
+    hs = host.HostScene.atrium(triangles, 12345)
+    assert hs.build_tree()["triangles"] == triangles
+    device.init(0)
+    ds = device.DeviceScene(hs.desc())
+    try:
+        c = cam_of(hs)
+        cams = [device.make_camera(c["eye"], c["angle"] + 0.7 * k, c["zoom"]) for k in range(3)]
+        kw = dict(model=device.MODEL_OMP, gi=True, rb=True, spp=16, gi_precision=device.GI_F32_FAST)
+        a = ds.render(**c, view=0, **kw)
+        hits = int((a["tri"] >= 0).sum())
+        assert a["stats"]["primary"] == 9 * 512 * 512
+        assert a["stats"]["gi"] == 16 * hits and a["stats"]["shadow"] == 0 and hits > 0.999 * 512 * 512
+        assert a["stats"]["omp_retrace"] >= 9 * hits                       # one per light and sub-ray hit
+        assert np.isfinite(a["rgb"]).all() and a["rgb"].min() >= 0
+        # independent of the number of passes the samples are traced in
+        os.environ["PT_TUNE_PASS_RAYS"] = str(5 << 18)                     # 5 samples per pass: 4 passes
+        try:
+            b = ds.render(**c, view=0, **kw)
+        finally:
+            del os.environ["PT_TUNE_PASS_RAYS"]
+        assert b["stats"]["gi_trace_launches"] == 4 and a["stats"]["gi_trace_launches"] == 1
+        assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["bgr"], b["bgr"])
+        # independent of view order, and the same inside the view loop of the C ABI
+        frames, st = ds.render_views(cams, view0=0, view_stride=1, size=512, **kw)
+        assert np.array_equal(frames[0], a["bgr"])
+        last_first = [ds.render(list(cams[k].eye), cams[k].angle, cams[k].zoom, view=k, aov=False, **kw)["bgr"] for k in (2, 1, 0)]
+        for k in range(3):
+            assert np.array_equal(frames[k], last_first[2 - k]), k
+        assert st["primary"] == 3 * 9 * 512 * 512
+        # the bundle only anti-aliases: same hits for the centre ray, nearly the same image
+        plain = ds.render(**c, view=0, **dict(kw, rb=False))
+        assert np.array_equal(plain["tri"], a["tri"]) and np.array_equal(plain["t"], a["t"])
+        assert abs(plain["rgb"].mean() - a["rgb"].mean()) < 2e-3
+        # fp64 GI at the same samples
+        e = ds.render(**c, view=0, **dict(kw, gi_precision=device.GI_F64_EXACT))
+        assert float(np.sqrt(np.mean((a["rgb"] - e["rgb"]) ** 2))) < 2e-3
+        assert (a["bgr"] != e["bgr"]).mean() < 1e-3
+        for k in ("tri", "t", "ghit", "gnrm"):
+            assert np.array_equal(a[k], e[k])
+    finally:
+        ds.close()
+
+
 @pytest.mark.parametrize("size,spp", [(1, 1), (7, 3), (33, 70), (100, 200), (64, 129)])
 def test_fast_path_ragged_sizes(gpu_scenes, host_scenes, size, spp):
     """Image sides that are not multiples of the 8-pixel tile (and not a power of two of tiles), sample counts
