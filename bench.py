@@ -6,8 +6,8 @@
 A step is one 512x512 view rendered per GPU (primary + mirror + shadow rays in
 fp64, GI sample rays through the fp32 wavefront path), the frame left in device
 memory and gathered to rank 0.  With N > 1 (one process per GPU, launched by
-torch.distributed.run) rank 0 reads the scene, builds the kd-tree and hands
-the packed scene to the other ranks with one RCCL broadcast; step i renders
+torch.distributed.run) rank 0 reads the scene, builds the trees, uploads the
+scene and hands its device data to the other ranks with one RCCL broadcast; step i renders
 camera i of the path on every rank under the RNG key of view i * N + rank of
 the multi-view job (equal work per GPU for every N), the frames go to rank 0
 in one gather per 8 steps, and no other collective touches the data path.
@@ -261,15 +261,14 @@ def main():
 
     # ---- scene: read + kd build on rank 0, RCCL broadcast of the packed blob ----
     t_scene = time.time()
-    hs = st = None
+    hs = st = ds = None
     if rank == 0:
         hs, st, views = load_host_scene(a.workload)
-        blob = device.scene_blob(hs.desc())
+        ds = device.DeviceScene(hs.desc())                    # the one place the scene is prepared (fp32 tree included)
         cams = np.array([[*v.eye, v.angle, v.zoom] for v in views])
     if world > 1:
-        blob = multiview.broadcast_bytes(blob if rank == 0 else None, xdev, dist)   # the scene + kd-tree travel over xGMI once
+        ds = multiview.broadcast_scene(ds, xdev, dist)        # the scene's device data travels over xGMI once, GPU to GPU
         cams = multiview.broadcast_cameras(cams if rank == 0 else None, xdev, dist)
-    ds = device.DeviceScene(blob=blob)
     scene_seconds = time.time() - t_scene
     views = [device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])) for c in cams]
     nviews = len(views)

@@ -127,10 +127,13 @@ typedef struct PtStats {
 
 typedef struct PtScene PtScene;
 
-/* Select the device for the calling process; device < 0 picks device 0.
-   Fails with PT_ERR_NO_DEVICE when there is no gfx950 GPU. */
+/* Select the device(s) of the calling process: device >= 0 that one; device < 0 every visible device -- scenes are
+   then uploaded to the first of them and pt_render_views shards its views over all (the library copies the scene to
+   the others with one RCCL broadcast when it first needs them).  mainOMP.cpp:344-346 (MPI_Init, world size) is the
+   nearest counterpart.  Fails with PT_ERR_NO_DEVICE when a selected device is not a gfx950 GPU. */
 int pt_init(int device);
 int pt_shutdown(void);
+int pt_device_count(void);    /* devices selected by pt_init, 0 before it */
 const char *pt_last_error(void);
 const char *pt_version(void);
 
@@ -153,6 +156,14 @@ int pt_scene_blob_size(const PtSceneDesc *desc, size_t *bytes);
 int pt_scene_blob_write(const PtSceneDesc *desc, void *blob, size_t bytes);
 int pt_scene_upload_blob(const void *blob, size_t bytes, PtScene **out);
 
+/* A built scene as one position-independent block of device data (everything pt_scene_upload prepares, the fp32 tree
+   included), for handing it to another GPU or process without preparing it again -- every MPI rank of the reference
+   reads the scene and builds the tree for itself (mainOMP.cpp:338-339).  dst / src are host memory, or device memory
+   of the current device when the *_is_device flag is set (the payload of an RCCL broadcast can be used in place). */
+int pt_scene_slab_size(const PtScene *scene, size_t *bytes);
+int pt_scene_slab_export(const PtScene *scene, void *dst, size_t bytes, int dst_is_device);
+int pt_scene_upload_slab(const void *src, size_t bytes, int src_is_device, PtScene **out);
+
 /* render(eye, zoom, angle) of main.cpp:109-147 (PT_MODEL_MAIN) or the per-pixel
    render() + row gather of mainOMP.cpp:111-136,185-197 (PT_MODEL_OMP).
    bgr_out receives size*size*3 bytes, exactly what `image` would hold. */
@@ -166,7 +177,10 @@ int pt_render_view_device(PtScene *scene, const PtCamera *cam, const PtOptions *
 
 /* The view loop of renderMultiple() (mainOMP.cpp:225-247) for the views this
    process owns: n cameras -> n frames of size*size*3 bytes each, view index
-   of camera i = view0 + i * view_stride (used as the RNG key word). */
+   of camera i = view0 + i * view_stride (used as the RNG key word).
+   After pt_init(-1) on a machine with several GPUs the views are dealt round-robin to one worker thread per GPU
+   (the reference deals rows to MPI workers, mainOMP.cpp:169-174; here the unit is the view) and every GPU copies its
+   frames into `frames` itself.  The frames are the same bytes for any number of GPUs. */
 int pt_render_views(PtScene *scene, const PtCamera *cams, size_t n, uint32_t view0, uint32_t view_stride,
                     const PtOptions *opt, uint8_t *frames, PtStats *stats);
 

@@ -10,7 +10,9 @@
 //
 // Extensions, all optional: --model main|omp (default: main, or omp with -rm as
 // that flag belongs to mainOMP.cpp), --spp N, --exact-gi (fp64 GI), --out DIR,
-// --size N, --views N (limit of -rm), --device K, --keys "wasdlr..." (camera
+// --size N, --views N (limit of -rm), --device K, --gpus all (with -rm: every
+// visible GPU, the views dealt round-robin to them by pt_render_views -- the
+// `mpirun -n` of mainOMP.cpp:344-353 in one process), --keys "wasdlr..." (camera
 // steps of simulate(), one frame per key), --stdin (the same steps read from
 // standard input, one command per line: a key w a s d l r, "C x y z angle_deg"
 // to place the camera, q to quit; one frame per command -- simulate() of
@@ -42,7 +44,7 @@ static int die(const char *what, const char *msg) {
 }
 
 int main(int argc, char **argv) {
-    bool gi = false, rb = false, rm = false, exact_gi = false, from_stdin = false;
+    bool gi = false, rb = false, rm = false, exact_gi = false, from_stdin = false, all_gpus = false;
     std::string scene, model_s, out = ".", keys, dataset;
     int spp = 0, size = 0, max_views = -1, dev = 0, noisy_spp = 4, converged_spp = 4096;
     for (int i = 1; i < argc; i++) {
@@ -60,6 +62,11 @@ int main(int argc, char **argv) {
         else if (a == "--size") size = std::atoi(val("--size"));
         else if (a == "--views") max_views = std::atoi(val("--views"));
         else if (a == "--device") dev = std::atoi(val("--device"));
+        else if (a == "--gpus") {
+            const std::string g = val("--gpus");
+            if (g == "all") all_gpus = true;
+            else if (g != "1") { std::fprintf(stderr, "ptmain: --gpus takes 1 or all (choose among GPUs with HIP_VISIBLE_DEVICES)\n"); return 2; }
+        }
         else if (a == "--out") out = val("--out");
         else if (a == "--keys") keys = val("--keys");
         else if (a == "--exact-gi") exact_gi = true;
@@ -86,7 +93,8 @@ int main(int argc, char **argv) {
                 (long long)ts.optimized);
     PtSceneDesc desc;
     if (pth_scene_desc(hs, &desc)) return die("scene", pth_last_error());
-    if (pt_init(dev)) return die("pt_init", pt_last_error());
+    if (pt_init(all_gpus ? -1 : dev)) return die("pt_init", pt_last_error());
+    if (rm) std::printf("World Size: %d\n", pt_device_count());              // mainOMP.cpp:349
     PtScene *ds = nullptr;
     if (pt_scene_upload(&desc, &ds)) return die("pt_scene_upload", pt_last_error());
 
@@ -129,6 +137,30 @@ int main(int argc, char **argv) {
             mkdir(dataset.c_str(), 0777);
             mkdir((dataset + "/" + upper).c_str(), 0777);
             for (const char *sub : {"4ssp", "4096ssp", "dif"}) mkdir((dataset + "/" + upper + "/" + upper + sub).c_str(), 0777);
+        }
+        if (dataset.empty() && all_gpus) {
+            // the view loop inside the library: batches of views, sharded over the GPUs, frames written between batches
+            const size_t batch = 8 * (size_t)pt_device_count();
+            std::vector<uint8_t> frames(batch * frame.size());
+            PtStats st{};
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (size_t v0 = 0; v0 < total; v0 += batch) {
+                const size_t nb = total - v0 < batch ? total - v0 : batch;
+                auto tb = std::chrono::high_resolution_clock::now();
+                if (pt_render_views(ds, cams.data() + v0, nb, (uint32_t)v0, 1, &opt, frames.data(), &st)) return die("pt_render_views", pt_last_error());
+                std::chrono::duration<double> el = std::chrono::high_resolution_clock::now() - tb;
+                for (size_t k = 0; k < nb; k++) {
+                    char name[64];
+                    std::snprintf(name, sizeof name, "/%s%zu.ppm", scene.c_str(), v0 + k);
+                    std::printf("Elapsed time: %g s\n", el.count() / (double)nb);
+                    if (pth_write_ppm((out + name).c_str(), frames.data() + k * frame.size(), n, n)) return die("write", pth_last_error());
+                }
+            }
+            std::chrono::duration<double> el = std::chrono::high_resolution_clock::now() - t0;
+            const unsigned long long rays = st.primary + st.shadow + st.mirror + st.gi;
+            std::printf("%zu views on %d GPU(s) in %.3f s: %.2f views/s, %.1f Mrays/s\n", total, pt_device_count(), el.count(),
+                        (double)total / el.count(), (double)rays / el.count() * 1e-6);
+            total = 0;                                          // nothing left for the loop below
         }
         for (size_t v = 0; v < total; v++) {
             char name[64];

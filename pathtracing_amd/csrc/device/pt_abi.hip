@@ -2,6 +2,9 @@
 // rendering and raw ray queries on one MI355X.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -11,6 +14,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pathtracing_amd.h"
@@ -60,9 +64,23 @@ struct Workspace {
 
 }  // namespace
 
+// Header of a scene slab (the one device allocation that holds every immutable array of a scene).
+struct SlabHeader {
+    char magic[8];                    // "PTSLAB01"
+    uint64_t total_bytes;             // header + arrays
+    DevScene S;                       // pointer fields of PT_SLAB_POINTERS: byte offsets from the slab's start; scratch pointers null
+    RefineStats refine;
+    int32_t max_depth;                // host tree
+    uint32_t n_tri, n_mesh;
+    uint64_t check;                   // header_check() of this header with this field zero
+};
+
 struct PtScene {
     DevScene S{};
-    std::vector<void *> owned;        // device allocations of the scene
+    int device = 0;
+    uint8_t *slab = nullptr;          // device memory: SlabHeader, then the arrays
+    size_t slab_bytes = 0;
+    std::vector<void *> owned;        // the scene's scratch allocations (overflow stacks, limit word)
     Workspace ws;
     hipStream_t stream = nullptr;
     hipStream_t stream_gen = nullptr;         // ray generation of the next GI pass runs here, beside the current pass
@@ -73,22 +91,35 @@ struct PtScene {
     uint64_t dev_bytes = 0;
     uint32_t n_tri = 0, n_mesh = 0;
     std::vector<int32_t> tri_mesh, tri_local;   // host copies for (mesh, tri) reporting
+    std::vector<PtScene *> replicas;            // copies of this scene on the other initialised devices (pt_render_views)
 };
 
 namespace {
 
-template <typename T>
-int dev_copy(PtScene *sc, const T *src, size_t n, const T **out) {
-    void *d = nullptr;
-    size_t bytes = (n ? n : 1) * sizeof(T);
-    HIPCHK(hipMalloc(&d, bytes));
-    sc->owned.push_back(d);
-    sc->dev_bytes += bytes;
-    if (n) HIPCHK(hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
-    *out = (const T *)d;
-    return PT_OK;
+std::vector<int> g_devices;           // the devices pt_init selected; g_device is the first of them
+
+uint64_t header_check(SlabHeader h) {
+    h.check = 0;
+    const uint8_t *p = (const uint8_t *)&h;
+    uint64_t a = 0xCBF29CE484222325ull;
+    for (size_t i = 0; i < sizeof h; i++) a = (a ^ p[i]) * 0x100000001B3ull;
+    return a;
 }
 
+// Host image of a slab under construction: arrays are appended at 256-byte boundaries and their offsets recorded in the
+// header's DevScene.
+struct SlabBuilder {
+    std::vector<uint8_t> bytes;
+    SlabHeader hdr{};
+    SlabBuilder() { bytes.resize((sizeof(SlabHeader) + 255) & ~(size_t)255); }
+    template <typename T>
+    void add(const T *src, size_t n, const T *DevScene::*field) {
+        const size_t off = bytes.size(), nb = n * sizeof(T);
+        bytes.resize((off + (nb ? nb : 1) + 255) & ~(size_t)255);
+        if (nb) std::memcpy(bytes.data() + off, src, nb);
+        hdr.S.*field = (const T *)(uintptr_t)off;
+    }
+};
 template <typename T>
 int ws_alloc(Workspace &ws, size_t n, T **out) {
     void *d = nullptr;
@@ -173,9 +204,9 @@ int tree_depth(const PtSceneDesc *d, int *depth_out) {
     return PT_OK;
 }
 
-int upload(const PtSceneDesc *d, PtScene **out) {
-    if (g_device < 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not been called");
-    if (!out) return fail(PT_ERR_INVALID, "out pointer is null");
+// Everything the host prepares of a scene, as the host image of its slab: the fp64 tree and reference lists, the fp32
+// tree built from the triangles (pt_refine.hip), per-triangle shading records, textures, lights.
+int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
     int rc = validate_desc(d);
     if (rc) return rc;
     int depth = 0;
@@ -184,18 +215,12 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     if (depth + 1 > PT_STACK_MAX)
         return fail(PT_ERR_LIMIT, "kd-tree depth " + std::to_string(depth) + " exceeds the traversal stack (" +
                                       std::to_string(PT_STACK_MAX) + ")");
-    struct Free { void operator()(PtScene *p) const { pt_scene_free(p); } };
-    std::unique_ptr<PtScene, Free> holder(new (std::nothrow) PtScene());      // freed on every early return and on a throw
-    PtScene *sc = holder.get();
-    if (!sc) return fail(PT_ERR_OOM, "out of host memory");
-    auto bail = [](int code) { return code; };
-    sc->max_depth = depth;
-    sc->n_tri = d->n_tri; sc->n_mesh = d->n_mesh;
-    sc->tri_mesh.assign(d->tri_mesh, d->tri_mesh + d->n_tri);
-    sc->tri_local.assign(d->tri_local, d->tri_local + d->n_tri);
-    DevScene &S = sc->S;
+    SlabHeader &H = B.hdr;
+    H.max_depth = depth;
+    H.n_tri = d->n_tri; H.n_mesh = d->n_mesh;
+    DevScene &S = H.S;
 
-    // ---- tree: fp64 traversal nodes + boxes, fp32 nodes ----
+    // ---- tree: fp64 traversal nodes + boxes ----
     std::vector<NodeA> na(d->n_node);
     std::vector<double> nbox((size_t)d->n_node * 6);
     for (uint32_t k = 0; k < d->n_node; k++) {
@@ -203,7 +228,7 @@ int upload(const PtSceneDesc *d, PtScene **out) {
         na[k].split = n.split; na[k].axis = n.axis; na[k].left = n.left; na[k].first = n.first; na[k].count = n.count;
         for (int c = 0; c < 3; c++) { nbox[6 * (size_t)k + c] = n.lo[c]; nbox[6 * (size_t)k + 3 + c] = n.hi[c]; }
     }
-    // ---- fp32 copy of the tree, fat leaves subdivided (pt_refine.hip) ----
+    // ---- fp32 tree (pt_refine.hip) ----
     std::vector<NodeF> nf;
     std::vector<int32_t> frefs;
     RefineParams rp;
@@ -211,9 +236,9 @@ int upload(const PtSceneDesc *d, PtScene **out) {
     if (const char *e = getenv("PT_TUNE_REFINE")) { rp.enable = atoi(e) != 0; rp.rebuild = atoi(e) == 2; }
     if (const char *e = getenv("PT_TUNE_CI")) rp.ci = (float)atof(e);
     if (const char *e = getenv("PT_TUNE_LEAF")) rp.leaf_keep = atoi(e);
-    sc->refine = refine_tree(d, rp, nf, frefs);
+    H.refine = refine_tree(d, rp, nf, frefs);
     if (nf.size() >= (1u << 28) || (uint64_t)frefs.size() * 48u >= (1ull << 32))
-        return bail(fail(PT_ERR_LIMIT, "kd-tree too large for 32-bit byte offsets (2^28 nodes, 2^32 / 48 references)"));
+        return fail(PT_ERR_LIMIT, "kd-tree too large for 32-bit byte offsets (2^28 nodes, 2^32 / 48 references)");
     // ---- per-reference triangle data in node order: v0, v1 - v0, v2 - v0 ----
     std::vector<double> rt((size_t)d->n_ref * 9);
     auto tri9 = [&](int32_t t, double *o) {
@@ -254,53 +279,21 @@ int upload(const PtSceneDesc *d, PtScene **out) {
         size_t nb = (size_t)trows[k] * tcols[k] * 3;
         texels.insert(texels.end(), d->tex[k].bgr, d->tex[k].bgr + nb);
     }
-#define UP(expr) do { int rc_ = (expr); if (rc_) return bail(rc_); } while (0)
-    UP(dev_copy(sc, na.data(), na.size(), &S.nodeA));
-    UP(dev_copy(sc, nbox.data(), nbox.size(), &S.nodeBox));
-    UP(dev_copy(sc, nf.data(), nf.size(), &S.nodeF));
-    UP(dev_copy(sc, rt.data(), rt.size(), &S.refTri));
-    UP(dev_copy(sc, rtf.data(), rtf.size(), &S.refTriF));
-    {
-        // overflow stack of the fp32 traversal: one column of (tree depth + 2) entries per lane of every
-        // wave the trace kernels are launched with
-        S.ovf_depth = (uint32_t)sc->refine.max_depth + 2u;
-        // PT_TUNE_OVF_DEPTH: a smaller stack than the tree needs, for the test of the limit report
-        if (const char *e = getenv("PT_TUNE_OVF_DEPTH")) { int k = atoi(e); if (k >= 1 && (uint32_t)k < S.ovf_depth) S.ovf_depth = (uint32_t)k; }
-        S.ovf_waves = PT_TRACE_WAVES;
-        void *p = nullptr;
-        size_t bytes = (size_t)S.ovf_waves * S.ovf_depth * 64 * sizeof(uint2);
-        if (hipMalloc(&p, bytes) != hipSuccess) return bail(fail(PT_ERR_OOM, "out of device memory (traversal overflow stack)"));
-        sc->owned.push_back(p);
-        sc->dev_bytes += bytes;
-        S.ovf = (uint2 *)p;
-    }
-    {
-        // overflow of the fp64 search's stack: beyond its LDS ring a lane needs at most one entry per tree level
-        S.ovf64_entries = (uint32_t)depth + 2u;
-        void *p = nullptr;
-        size_t bytes = (size_t)PT_EXACT_WAVES * S.ovf64_entries * 64 * 3 * sizeof(double);
-        if (hipMalloc(&p, bytes) != hipSuccess) return bail(fail(PT_ERR_OOM, "out of device memory (fp64 stack overflow)"));
-        sc->owned.push_back(p);
-        sc->dev_bytes += bytes;
-        S.ovf64 = (double *)p;
-    }
-    {
-        void *p = nullptr;
-        if (hipMalloc(&p, sizeof(unsigned long long)) != hipSuccess) return bail(fail(PT_ERR_OOM, "out of device memory"));
-        sc->owned.push_back(p);
-        S.err = (unsigned long long *)p;
-        HIPCHK(hipMemset(p, 0, sizeof(unsigned long long)));
-    }
-    UP(dev_copy(sc, tgeo.data(), tgeo.size(), &S.triGeo));
-    UP(dev_copy(sc, tng.data(), tng.size(), &S.triNgF));
-    UP(dev_copy(sc, d->refs, (size_t)d->n_ref, &S.refId));
-    UP(dev_copy(sc, d->tri_ni, (size_t)d->n_tri * 3, &S.tri_ni));
-    UP(dev_copy(sc, d->tri_ti, (size_t)d->n_tri * 3, &S.tri_ti));
-    UP(dev_copy(sc, d->tri_tm, (size_t)d->n_tri, &S.tri_tm));
-    UP(dev_copy(sc, d->tri_reft, (size_t)d->n_tri, &S.tri_reft));
-    UP(dev_copy(sc, d->tri_mesh, (size_t)d->n_tri, &S.tri_mesh));
-    UP(dev_copy(sc, d->tri_local, (size_t)d->n_tri, &S.tri_local));
-    UP(dev_copy(sc, d->norm, (size_t)d->n_norm * 3, &S.norm));
+    B.add(na.data(), na.size(), &DevScene::nodeA);
+    B.add(nbox.data(), nbox.size(), &DevScene::nodeBox);
+    B.add(nf.data(), nf.size(), &DevScene::nodeF);
+    B.add(rt.data(), rt.size(), &DevScene::refTri);
+    B.add(rtf.data(), rtf.size(), &DevScene::refTriF);
+    B.add(tgeo.data(), tgeo.size(), &DevScene::triGeo);
+    B.add(tng.data(), tng.size(), &DevScene::triNgF);
+    B.add(d->refs, (size_t)d->n_ref, &DevScene::refId);
+    B.add(d->tri_ni, (size_t)d->n_tri * 3, &DevScene::tri_ni);
+    B.add(d->tri_ti, (size_t)d->n_tri * 3, &DevScene::tri_ti);
+    B.add(d->tri_tm, (size_t)d->n_tri, &DevScene::tri_tm);
+    B.add(d->tri_reft, (size_t)d->n_tri, &DevScene::tri_reft);
+    B.add(d->tri_mesh, (size_t)d->n_tri, &DevScene::tri_mesh);
+    B.add(d->tri_local, (size_t)d->n_tri, &DevScene::tri_local);
+    B.add(d->norm, (size_t)d->n_norm * 3, &DevScene::norm);
     {
         std::vector<float4> sh((size_t)d->n_tri * 5);
         for (uint32_t t = 0; t < d->n_tri; t++) {
@@ -320,15 +313,15 @@ int upload(const PtSceneDesc *d, PtScene **out) {
             o[3] = make_float4(uv[3], uv[4], uv[5], bits_to_float(d->tri_tm[t]));
             o[4] = make_float4((float)al[0], (float)al[1], (float)al[2], 0.f);
         }
-        UP(dev_copy(sc, sh.data(), sh.size(), &S.triShadeF));
+        B.add(sh.data(), sh.size(), &DevScene::triShadeF);
     }
-    UP(dev_copy(sc, d->uv, (size_t)d->n_uv * 2, &S.uv));
-    UP(dev_copy(sc, d->mesh_albedo, (size_t)d->n_mesh * 3, &S.albedo));
-    UP(dev_copy(sc, texels.data(), texels.size(), &S.texels));
-    UP(dev_copy(sc, toff.data(), toff.size(), &S.tex_off));
-    UP(dev_copy(sc, trows.data(), trows.size(), &S.tex_rows));
-    UP(dev_copy(sc, tcols.data(), tcols.size(), &S.tex_cols));
-    UP(dev_copy(sc, d->lights, (size_t)d->n_light, &S.lights));
+    B.add(d->uv, (size_t)d->n_uv * 2, &DevScene::uv);
+    B.add(d->mesh_albedo, (size_t)d->n_mesh * 3, &DevScene::albedo);
+    B.add(texels.data(), texels.size(), &DevScene::texels);
+    B.add(toff.data(), toff.size(), &DevScene::tex_off);
+    B.add(trows.data(), trows.size(), &DevScene::tex_rows);
+    B.add(tcols.data(), tcols.size(), &DevScene::tex_cols);
+    B.add(d->lights, (size_t)d->n_light, &DevScene::lights);
     {
         std::vector<float4> lf(2 * (size_t)d->n_light);
         for (uint32_t k = 0; k < d->n_light; k++) {
@@ -336,9 +329,8 @@ int upload(const PtSceneDesc *d, PtScene **out) {
             lf[2 * k] = make_float4((float)L.pos[0], (float)L.pos[1], (float)L.pos[2], bits_to_float(L.type));
             lf[2 * k + 1] = make_float4((float)(L.mag * L.color[0]), (float)(L.mag * L.color[1]), (float)(L.mag * L.color[2]), 0.f);
         }
-        UP(dev_copy(sc, lf.data(), lf.size(), &S.lightsF));
+        B.add(lf.data(), lf.size(), &DevScene::lightsF);
     }
-#undef UP
     S.any_mirror = 0;
     for (uint32_t t = 0; t < d->n_tri; t++) S.any_mirror |= d->tri_reft[t] != 0;
     S.n_light = (int32_t)d->n_light; S.n_node = (int32_t)d->n_node; S.n_ref = (int32_t)d->n_ref; S.n_tri = (int32_t)d->n_tri;
@@ -347,13 +339,96 @@ int upload(const PtSceneDesc *d, PtScene **out) {
         S.root_lo[k] = d->nodes[0].lo[k];
         S.root_hi[k] = d->nodes[0].hi[k];
     }
+    // sizes of the scratch every copy of the scene allocates for itself
+    S.ovf_depth = (uint32_t)H.refine.max_depth + 2u;
+    // PT_TUNE_OVF_DEPTH: a smaller stack than the tree needs, for the test of the limit report
+    if (const char *e = getenv("PT_TUNE_OVF_DEPTH")) { int k = atoi(e); if (k >= 1 && (uint32_t)k < S.ovf_depth) S.ovf_depth = (uint32_t)k; }
+    S.ovf_waves = PT_TRACE_WAVES;
+    S.ovf64_entries = (uint32_t)depth + 2u;
+    std::memcpy(H.magic, "PTSLAB01", 8);
+    H.total_bytes = B.bytes.size();
+    H.check = 0;
+    H.check = header_check(H);
+    std::memcpy(B.bytes.data(), &H, sizeof H);
+    return PT_OK;
+}
+
+int check_slab_header(const SlabHeader &H, size_t bytes) {
+    if (std::memcmp(H.magic, "PTSLAB01", 8) != 0 || H.total_bytes != bytes || bytes < sizeof(SlabHeader) || H.check != header_check(H))
+        return fail(PT_ERR_INVALID, "not a scene slab of this library version, or damaged");
+#define X(f) if ((uintptr_t)H.S.f < sizeof(SlabHeader) || (uintptr_t)H.S.f >= bytes) return fail(PT_ERR_INVALID, "scene slab: array offset out of range");
+    PT_SLAB_POINTERS(X)
+#undef X
+    return PT_OK;
+}
+
+// A scene on the current device around a slab that is already there (`slab`, owned by the scene from here on): binds the
+// pointers, allocates the scene's own scratch, streams and events, fetches the two host-side index tables.
+int finish_scene(uint8_t *slab, const SlabHeader &H, int device, PtScene **out) {
+    struct Free { void operator()(PtScene *p) const { pt_scene_free(p); } };
+    std::unique_ptr<PtScene, Free> holder(new (std::nothrow) PtScene());
+    PtScene *sc = holder.get();
+    if (!sc) { (void)hipFree(slab); return fail(PT_ERR_OOM, "out of host memory"); }
+    sc->slab = slab; sc->slab_bytes = (size_t)H.total_bytes; sc->device = device;
+    sc->dev_bytes = H.total_bytes;
+    sc->max_depth = H.max_depth; sc->refine = H.refine; sc->n_tri = H.n_tri; sc->n_mesh = H.n_mesh;
+    DevScene &S = sc->S;
+    S = H.S;
+#define X(f) S.f = (decltype(S.f))(slab + (uintptr_t)H.S.f);
+    PT_SLAB_POINTERS(X)
+#undef X
+    auto scratch = [&](size_t bytes, void **p) -> int {
+        if (hipMalloc(p, bytes) != hipSuccess) return fail(PT_ERR_OOM, "out of device memory (scene scratch)");
+        sc->owned.push_back(*p);
+        sc->dev_bytes += bytes;
+        return PT_OK;
+    };
+    int rc;
+    // overflow stack of the fp32 traversal: one column of (tree depth + 2) entries per lane of every wave of a trace launch
+    if ((rc = scratch((size_t)S.ovf_waves * S.ovf_depth * 64 * sizeof(uint2), (void **)&S.ovf))) return rc;
+    // overflow of the fp64 search's stack: beyond its LDS ring a lane needs at most one entry per tree level
+    if ((rc = scratch((size_t)PT_EXACT_WAVES * S.ovf64_entries * 64 * 3 * sizeof(double), (void **)&S.ovf64))) return rc;
+    if ((rc = scratch(sizeof(unsigned long long), (void **)&S.err))) return rc;
+    HIPCHK(hipMemset(S.err, 0, sizeof(unsigned long long)));
+    sc->tri_mesh.resize(H.n_tri); sc->tri_local.resize(H.n_tri);
+    if (H.n_tri) {
+        HIPCHK(hipMemcpy(sc->tri_mesh.data(), S.tri_mesh, (size_t)H.n_tri * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(sc->tri_local.data(), S.tri_local, (size_t)H.n_tri * 4, hipMemcpyDeviceToHost));
+    }
     hipError_t e = hipStreamCreate(&sc->stream);
     if (e == hipSuccess) e = hipStreamCreate(&sc->stream_gen);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev0);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
-    if (e != hipSuccess) return bail(fail(PT_ERR_HIP, std::string("stream/event creation: ") + hipGetErrorString(e)));
+    if (e != hipSuccess) return fail(PT_ERR_HIP, std::string("stream/event creation: ") + hipGetErrorString(e));
     *out = holder.release();
     return PT_OK;
+}
+
+// A scene on device g_device from a slab image in host or device memory.
+int scene_from_slab(const void *src, size_t bytes, bool src_is_device, PtScene **out) {
+    if (g_device < 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not been called");
+    if (!out || !src) return fail(PT_ERR_INVALID, "null pointer");
+    if (bytes < sizeof(SlabHeader)) return fail(PT_ERR_INVALID, "not a scene slab (too small)");
+    SlabHeader H;
+    if (src_is_device) HIPCHK(hipMemcpy(&H, src, sizeof H, hipMemcpyDeviceToHost));
+    else std::memcpy(&H, src, sizeof H);
+    int rc = check_slab_header(H, bytes);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(g_device));
+    void *slab = nullptr;
+    if (hipMalloc(&slab, bytes) != hipSuccess) return fail(PT_ERR_OOM, "out of device memory (scene slab)");
+    hipError_t e = hipMemcpy(slab, src, bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(slab); return fail(PT_ERR_HIP, std::string("scene slab copy: ") + hipGetErrorString(e)); }
+    return finish_scene((uint8_t *)slab, H, g_device, out);
+}
+
+int upload(const PtSceneDesc *d, PtScene **out) {
+    if (g_device < 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not been called");
+    if (!out) return fail(PT_ERR_INVALID, "out pointer is null");
+    SlabBuilder B;
+    int rc = build_slab(d, B);
+    if (rc) return rc;
+    return scene_from_slab(B.bytes.data(), B.bytes.size(), false, out);
 }
 
 // The limit word of the scene after the kernels of a call have finished (the caller has synchronised the scene's
@@ -503,6 +578,124 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     return PT_OK;
 }
 
+// ---- copies of a scene on the other initialised devices -------------------------------------------------------
+// RCCL is loaded when it is first needed (a process that runs on one GPU, or under torch.distributed with its own
+// RCCL, never touches it).
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+};
+Rccl g_rccl;
+
+int rccl_comms(const std::vector<int> &devs) {
+    Rccl &R = g_rccl;
+    if (!R.lib) {
+        R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!R.lib) return fail(PT_ERR_NO_DEVICE, std::string("RCCL could not be loaded: ") + dlerror());
+#define SYM(field, name) R.field = (decltype(R.field))dlsym(R.lib, name); if (!R.field) return fail(PT_ERR_NO_DEVICE, "RCCL lacks " name)
+        SYM(CommInitAll, "ncclCommInitAll"); SYM(Broadcast, "ncclBroadcast"); SYM(GroupStart, "ncclGroupStart");
+        SYM(GroupEnd, "ncclGroupEnd"); SYM(CommDestroy, "ncclCommDestroy"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    }
+    if (R.devices == devs) return PT_OK;
+    for (ncclComm_t c : R.comms) (void)R.CommDestroy(c);
+    R.comms.assign(devs.size(), nullptr);
+    R.devices.clear();
+    ncclResult_t r = R.CommInitAll(R.comms.data(), (int)devs.size(), devs.data());
+    if (r != ncclSuccess) { R.comms.clear(); return fail(PT_ERR_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(r)); }
+    R.devices = devs;
+    return PT_OK;
+}
+
+// The devices the view loop runs on: those of pt_init, or -- PT_TUNE_REPLICAS=k, a rehearsal for machines with one
+// GPU -- k workers that all use the first device.
+std::vector<int> worker_devices() {
+    std::vector<int> devs = g_devices;
+    if (const char *e = getenv("PT_TUNE_REPLICAS")) {
+        const int k = atoi(e);
+        if (k >= 1 && k <= 16) devs.assign((size_t)k, g_device);
+    }
+    return devs;
+}
+
+// Makes sure `sc` has a copy on every worker device but the first.  The slab -- every immutable array of the scene,
+// the fp32 tree included -- goes from the first device to the others in ONE broadcast over xGMI (RCCL; a single
+// collective of the scene's size, no host round trip, nothing rebuilt).  Workers that share the first device (the
+// rehearsal) get a device-to-device copy, or, with PT_TUNE_RCCL_SELF=1, a broadcast in a communicator of one rank, so
+// that the RCCL calls are exercised on a one-GPU machine too.
+int ensure_replicas(PtScene *sc, const std::vector<int> &devs) {
+    if (sc->replicas.size() + 1 == devs.size()) {
+        bool same = true;
+        for (size_t k = 1; k < devs.size(); k++) same = same && sc->replicas[k - 1]->device == devs[k];
+        if (same) return PT_OK;
+    }
+    for (PtScene *r : sc->replicas) pt_scene_free(r);
+    sc->replicas.clear();
+    if (devs.size() <= 1) return PT_OK;
+    SlabHeader H;
+    HIPCHK(hipSetDevice(sc->device));
+    HIPCHK(hipMemcpy(&H, sc->slab, sizeof H, hipMemcpyDeviceToHost));
+    bool distinct = true;
+    for (size_t a = 0; a < devs.size(); a++)
+        for (size_t b = a + 1; b < devs.size(); b++) distinct = distinct && devs[a] != devs[b];
+    const bool self = !distinct && getenv("PT_TUNE_RCCL_SELF") && atoi(getenv("PT_TUNE_RCCL_SELF")) == 1;
+    std::vector<uint8_t *> slabs(devs.size(), nullptr);
+    slabs[0] = sc->slab;
+    auto release = [&]() { for (size_t k = 1; k < slabs.size(); k++) if (slabs[k]) { (void)hipSetDevice(devs[k]); (void)hipFree(slabs[k]); } (void)hipSetDevice(sc->device); };
+    for (size_t k = 1; k < devs.size(); k++) {
+        if (hipSetDevice(devs[k]) != hipSuccess || hipMalloc((void **)&slabs[k], sc->slab_bytes) != hipSuccess) {
+            release();
+            return fail(PT_ERR_OOM, "out of device memory (scene copy on device " + std::to_string(devs[k]) + ")");
+        }
+    }
+    int rc = PT_OK;
+    if (distinct) {
+        rc = rccl_comms(devs);
+        if (!rc) {
+            Rccl &R = g_rccl;
+            ncclResult_t r = R.GroupStart();
+            for (size_t k = 0; k < devs.size() && r == ncclSuccess; k++) {
+                (void)hipSetDevice(devs[k]);
+                r = R.Broadcast(sc->slab, slabs[k], sc->slab_bytes, ncclUint8, 0, R.comms[k], nullptr);
+            }
+            ncclResult_t r2 = R.GroupEnd();
+            if (r == ncclSuccess) r = r2;
+            for (size_t k = 0; k < devs.size(); k++) { (void)hipSetDevice(devs[k]); (void)hipDeviceSynchronize(); }
+            if (r != ncclSuccess) rc = fail(PT_ERR_HIP, std::string("ncclBroadcast of the scene: ") + R.GetErrorString(r));
+        }
+    } else if (self) {
+        rc = rccl_comms(std::vector<int>{sc->device});
+        for (size_t k = 1; k < devs.size() && !rc; k++) {
+            ncclResult_t r = g_rccl.Broadcast(sc->slab, slabs[k], sc->slab_bytes, ncclUint8, 0, g_rccl.comms[0], nullptr);
+            if (r != ncclSuccess) rc = fail(PT_ERR_HIP, std::string("ncclBroadcast of the scene: ") + g_rccl.GetErrorString(r));
+        }
+        (void)hipDeviceSynchronize();
+    } else {
+        for (size_t k = 1; k < devs.size() && !rc; k++)
+            if (hipMemcpy(slabs[k], sc->slab, sc->slab_bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = fail(PT_ERR_HIP, "scene copy failed");
+    }
+    if (rc) { release(); return rc; }
+    for (size_t k = 1; k < devs.size(); k++) {
+        (void)hipSetDevice(devs[k]);
+        PtScene *r = nullptr;
+        uint8_t *slab = slabs[k];
+        slabs[k] = nullptr;                                  // owned by the copy (or freed by finish_scene) from here on
+        rc = finish_scene(slab, H, devs[k], &r);
+        if (rc) { release(); for (PtScene *q : sc->replicas) pt_scene_free(q); sc->replicas.clear(); return rc; }
+        sc->replicas.push_back(r);
+    }
+    HIPCHK(hipSetDevice(sc->device));
+    return PT_OK;
+}
+
 template <typename T>
 int fetch(PtScene *sc, T *host, const T *dev, size_t n) {
     if (!host) return PT_OK;
@@ -521,21 +714,31 @@ int pt_init(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device is visible");
-    int dev = device < 0 ? 0 : device;
-    if (dev >= n) return fail(PT_ERR_NO_DEVICE, "device ordinal " + std::to_string(dev) + " out of range (" + std::to_string(n) + " visible)");
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, dev));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(PT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-    HIPCHK(hipSetDevice(dev));
-    // address of this device's copy of the fixed scratch array (pt_trace_device)
-    if (int rc = static_scratch_setup(dev))
-        return fail(rc, "the address of the library's scratch array could not be taken on device " + std::to_string(dev));
-    g_device = dev;
+    if (device >= n) return fail(PT_ERR_NO_DEVICE, "device ordinal " + std::to_string(device) + " out of range (" + std::to_string(n) + " visible)");
+    // device >= 0: that device.  device < 0: every visible device -- scenes are uploaded to the first, and
+    // pt_render_views shards its views over all of them.
+    std::vector<int> devs;
+    for (int dev = device < 0 ? 0 : device; dev < (device < 0 ? n : device + 1); dev++) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, dev));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(PT_ERR_NO_DEVICE, std::string("device ") + std::to_string(dev) + " is " + prop.gcnArchName +
+                                              ", this library is built for gfx950 only");
+        HIPCHK(hipSetDevice(dev));
+        // address of this device's copy of the fixed scratch array (pt_trace_device)
+        if (int rc = static_scratch_setup(dev))
+            return fail(rc, "the address of the library's scratch array could not be taken on device " + std::to_string(dev));
+        devs.push_back(dev);
+    }
+    HIPCHK(hipSetDevice(devs[0]));
+    g_devices = devs;
+    g_device = devs[0];
     return PT_OK;
 }
 
-int pt_shutdown(void) { g_device = -1; return PT_OK; }
+int pt_shutdown(void) { g_device = -1; g_devices.clear(); return PT_OK; }
+
+int pt_device_count(void) { return (int)g_devices.size(); }
 
 int pt_scene_upload(const PtSceneDesc *desc, PtScene **out) { return guarded([&] { return upload(desc, out); }); }
 
@@ -552,13 +755,19 @@ int pt_scene_info(const PtScene *sc, PtSceneInfo *out) {
 
 int pt_scene_free(PtScene *sc) {
     if (!sc) return PT_OK;
+    for (PtScene *r : sc->replicas) pt_scene_free(r);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(sc->device);
     ws_release(sc->ws);
     for (void *p : sc->owned) (void)hipFree(p);
+    if (sc->slab) (void)hipFree(sc->slab);
     if (sc->ev0) (void)hipEventDestroy(sc->ev0);
     if (sc->ev1) (void)hipEventDestroy(sc->ev1);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
     if (sc->stream_gen) (void)hipStreamDestroy(sc->stream_gen);
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
+    if (prev >= 0) (void)hipSetDevice(prev);
     delete sc;
     return PT_OK;
 }
@@ -753,20 +962,77 @@ int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0,
     int rc = check_options(opt, &size, &N);
     if (rc) return rc;
     auto t0 = std::chrono::steady_clock::now();
-    size_t frame_bytes = (size_t)size * size * 3;
-    PtOptions o = *opt;
-    for (size_t i = 0; i < n; i++) {
-        o.view = view0 + (uint32_t)i * view_stride;
-        float gi_ms; uint64_t gi_l;
-        rc = render_on_device(sc, &cams[i], &o, stats, &gi_ms, &gi_l);
-        if (rc) return rc;
-        // the copy is ordered on the scene's stream; the next view's kernels follow it
-        HIPCHK(hipMemcpyAsync(frames + i * frame_bytes, sc->ws.F.bgr, frame_bytes, hipMemcpyDeviceToHost, sc->stream));
+    const size_t frame_bytes = (size_t)size * size * 3;
+    // One worker per device: worker w renders the views i with i % workers == w on its copy of the scene and copies
+    // each frame straight into the caller's array (every GPU over its own PCIe link; nothing is routed through the
+    // first GPU).  The frames do not depend on the number of workers: the RNG is keyed by the view index.
+    const std::vector<int> devs = worker_devices();
+    rc = ensure_replicas(sc, devs);
+    if (rc) return rc;
+    const size_t W = devs.size();
+    std::vector<int> wrc(W, PT_OK);
+    std::vector<std::string> werr(W);
+    std::vector<PtStats> wst(W);
+    auto work = [&](size_t w) {
+        PtScene *my = w == 0 ? sc : sc->replicas[w - 1];
+        PtStats *st = stats ? &wst[w] : nullptr;
+        if (st) std::memset(st, 0, sizeof *st);
+        int r = PT_OK;
+        if (hipSetDevice(my->device) != hipSuccess) r = fail(PT_ERR_HIP, "hipSetDevice failed in a view worker");
+        PtOptions o = *opt;
+        for (size_t i = w; i < n && !r; i += W) {
+            o.view = view0 + (uint32_t)i * view_stride;
+            float gi_ms; uint64_t gi_l;
+            r = render_on_device(my, &cams[i], &o, st, &gi_ms, &gi_l);
+            // the copy is ordered on the scene's stream; the next view's kernels follow it
+            if (!r && hipMemcpyAsync(frames + i * frame_bytes, my->ws.F.bgr, frame_bytes, hipMemcpyDeviceToHost, my->stream) != hipSuccess)
+                r = fail(PT_ERR_HIP, "frame copy failed");
+        }
+        if (!r && hipStreamSynchronize(my->stream) != hipSuccess) r = fail(PT_ERR_HIP, "stream synchronisation failed");
+        wrc[w] = r;
+        if (r) werr[w] = g_error;                          // the message lives in the worker's thread
+    };
+    if (W == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> threads;
+        for (size_t w = 0; w < W; w++) threads.emplace_back([&, w] { try { work(w); } catch (...) { wrc[w] = PT_ERR_OOM; werr[w] = "exception in a view worker"; } });
+        for (std::thread &t : threads) t.join();
+        (void)hipSetDevice(sc->device);
     }
-    HIPCHK(hipStreamSynchronize(sc->stream));
-    if (stats) stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t w = 0; w < W; w++)
+        if (wrc[w]) return fail(wrc[w], "view worker " + std::to_string(w) + " (device " + std::to_string(devs[w]) + "): " + werr[w]);
+    if (stats) {
+        for (size_t w = 0; w < W; w++) {
+            stats->primary += wst[w].primary; stats->shadow += wst[w].shadow; stats->mirror += wst[w].mirror; stats->gi += wst[w].gi;
+            stats->omp_retrace += wst[w].omp_retrace; stats->ms_gi_trace += wst[w].ms_gi_trace;
+            stats->gi_trace_launches += wst[w].gi_trace_launches; stats->gi_nodes_visited += wst[w].gi_nodes_visited;
+            stats->gi_tris_tested += wst[w].gi_tris_tested;
+        }
+        stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     return PT_OK;
 }); }
+
+// The scene's slab -- all of its immutable device arrays in one position-independent block -- copied out to host or
+// device memory, and a scene made from such a copy: how one process hands a built scene to another GPU or process
+// (e.g. as the payload of an RCCL broadcast) without reading, checking or building anything twice.
+int pt_scene_slab_size(const PtScene *sc, size_t *bytes) {
+    if (!sc || !bytes) return fail(PT_ERR_INVALID, "pt_scene_slab_size: null argument");
+    *bytes = sc->slab_bytes;
+    return PT_OK;
+}
+
+int pt_scene_slab_export(const PtScene *sc, void *dst, size_t bytes, int dst_is_device) {
+    if (!sc || !dst) return fail(PT_ERR_INVALID, "pt_scene_slab_export: null argument");
+    if (bytes < sc->slab_bytes) return fail(PT_ERR_INVALID, "pt_scene_slab_export: destination too small");
+    HIPCHK(hipMemcpy(dst, sc->slab, sc->slab_bytes, dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_scene_upload_slab(const void *src, size_t bytes, int src_is_device, PtScene **out) {
+    return guarded([&] { return scene_from_slab(src, bytes, src_is_device != 0, out); });
+}
 
 int pt_trace(PtScene *sc, size_t n, const double *src, const double *dir, const double *tmin_in, int mode,
              int32_t *found, int32_t *mesh, int32_t *tri, double *t, double *u, double *v) { return guarded([&]() -> int {

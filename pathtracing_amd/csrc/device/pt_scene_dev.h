@@ -72,5 +72,13 @@ struct DevScene {
 };
 
 // ray counters of a view, then the work counters the persistent primary / mirror kernels draw their blocks from
+// The immutable arrays of a DevScene live in ONE device allocation (the scene slab); these are the pointer fields that
+// point into it.  A slab is position independent: its header holds a DevScene whose pointer fields are byte offsets
+// from the slab's start, so a copy of the slab on another GPU (or in another process) becomes a scene by adding its
+// own base address -- no host preprocessing, no second build of the fp32 tree.
+#define PT_SLAB_POINTERS(X) \
+    X(nodeA) X(nodeBox) X(refTri) X(refId) X(nodeF) X(refTriF) X(triGeo) X(triNgF) X(tri_ni) X(tri_ti) X(tri_tm) X(tri_reft) \
+    X(tri_mesh) X(tri_local) X(norm) X(uv) X(albedo) X(triShadeF) X(texels) X(tex_off) X(tex_rows) X(tex_cols) X(lights) X(lightsF)
+
 enum { PT_LIMIT_F32_STACK = 1, PT_LIMIT_F32_STEPS = 2, PT_LIMIT_F64_STACK = 4 };
 enum { RC_PRIMARY = 0, RC_SHADOW = 1, RC_MIRROR = 2, RC_GI = 3, RC_RETRACE = 4, RC_WORK_PRIMARY = 5, RC_WORK_MIRROR = 6, RC_LIMITS = 7, RC_N = 8 };

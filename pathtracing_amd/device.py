@@ -41,7 +41,8 @@ class PtSceneInfo(C.Structure):
                                           "dev_interior_refs", "dev_bytes")] + [("host_depth", C.c_int32), ("dev_depth", C.c_int32)]
 
 
-EXPORTS = ("pt_scene_info", "pt_init", "pt_shutdown", "pt_last_error", "pt_version", "pt_scene_upload", "pt_scene_free",
+EXPORTS = ("pt_scene_info", "pt_init", "pt_shutdown", "pt_device_count", "pt_scene_slab_size", "pt_scene_slab_export",
+           "pt_scene_upload_slab", "pt_last_error", "pt_version", "pt_scene_upload", "pt_scene_free",
            "pt_scene_blob_size", "pt_scene_blob_write", "pt_scene_upload_blob", "pt_render_view",
            "pt_render_view_device", "pt_render_views", "pt_trace", "pt_trace_device", "pt_camera_rays", "pt_hemisphere_samples")
 
@@ -71,6 +72,9 @@ def lib():
         L.pt_render_views.argtypes = [C.c_void_p, C.POINTER(PtCamera), C.c_size_t, C.c_uint32, C.c_uint32,
                                       C.POINTER(PtOptions), C.c_void_p, C.POINTER(PtStats)]
         L.pt_trace.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 6
+        L.pt_scene_slab_size.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.pt_scene_slab_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.pt_scene_upload_slab.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.pt_trace_device.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9
         L.pt_camera_rays.argtypes = [C.POINTER(PtCamera), C.c_int, C.c_double, C.c_double, C.c_void_p]
         L.pt_hemisphere_samples.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
@@ -88,7 +92,12 @@ def _check(rc, what):
 
 
 def init(device=0):
+    """device >= 0: that GPU; -1: every visible GPU (pt_render_views then shards its views over them)."""
     _check(lib().pt_init(device), "pt_init")
+
+
+def device_count():
+    return lib().pt_device_count()
 
 
 def make_camera(eye, angle, zoom):
@@ -115,14 +124,28 @@ def scene_blob(desc):
 class DeviceScene:
     """A scene resident on the GPU (PtScene handle)."""
 
-    def __init__(self, desc=None, blob=None):
+    def __init__(self, desc=None, blob=None, slab=None):
+        """desc: a PtSceneDesc; blob: the scene description as bytes (pt_scene_blob_write); slab: (address, bytes,
+        is_device) of a built scene's device data (slab_export of another DeviceScene, possibly in another process)."""
         h = C.c_void_p()
-        if blob is not None:
+        if slab is not None:
+            ptr, nbytes, is_device = slab
+            _check(lib().pt_scene_upload_slab(C.c_void_p(ptr), nbytes, int(is_device), C.byref(h)), "pt_scene_upload_slab")
+        elif blob is not None:
             blob = np.ascontiguousarray(blob, np.uint8)
             _check(lib().pt_scene_upload_blob(blob.ctypes.data, blob.size, C.byref(h)), "pt_scene_upload_blob")
         else:
             _check(lib().pt_scene_upload(C.byref(desc), C.byref(h)), "pt_scene_upload")
         self._h = h
+
+    def slab_size(self):
+        n = C.c_size_t()
+        _check(lib().pt_scene_slab_size(self._h, C.byref(n)), "pt_scene_slab_size")
+        return n.value
+
+    def slab_export(self, ptr, nbytes, is_device):
+        """Copy the scene's device data (one position-independent block) to host or device memory at `ptr`."""
+        _check(lib().pt_scene_slab_export(self._h, C.c_void_p(ptr), nbytes, int(is_device)), "pt_scene_slab_export")
 
     def info(self):
         i = PtSceneInfo()

@@ -7,8 +7,10 @@ distribution is the view: views are independent, so view v goes to rank
 v % world and the data path needs no collective.  The two exchanges that
 remain are
 
-* once per job: rank 0 reads the scene, builds the tree and broadcasts the
-  packed scene blob (RCCL over xGMI when the tensors live on GPUs);
+* once per job: rank 0 reads the scene, builds the trees, uploads the scene and
+  broadcasts its device data -- one position-independent block, GPU to GPU over
+  xGMI with RCCL when the tensors live on GPUs -- which the other ranks turn
+  into their scene without preparing anything again;
 * per batch of rounds: the finished BGR8 frames are gathered on rank 0.  A gather makes the ranks wait for each
   other, and views differ in cost by tens of percent, so the ranks render several views each (8 by default) between
   two gathers instead of meeting after every view.
@@ -48,6 +50,30 @@ def broadcast_bytes(payload, device, dist, src=0):
         buf.copy_(torch.from_numpy(np.ascontiguousarray(payload, np.uint8)))
     dist.broadcast(buf, src)
     return buf.cpu().numpy()
+
+
+def broadcast_scene(scene, device, dist, src=0):
+    """Rank `src` holds a DeviceScene; every other rank passes None and gets one made from the broadcast copy of its
+    device data (the slab: all immutable arrays, the fp32 tree included).  With `device` a GPU the payload is exported
+    device to device, broadcast by RCCL and imported device to device; with a CPU device (gloo rehearsal) it is staged
+    through host memory.  Returns the rank's DeviceScene."""
+    import torch
+    from . import device as ptdev
+    rank = dist.get_rank()
+    on_gpu = torch.device(device).type == "cuda"
+    n = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == src:
+        n[0] = scene.slab_size()
+    dist.broadcast(n, src)
+    buf = torch.empty(int(n[0]), dtype=torch.uint8, device=device)
+    if rank == src:
+        scene.slab_export(buf.data_ptr(), buf.numel(), on_gpu)
+    dist.broadcast(buf, src)
+    if rank == src:
+        return scene
+    if on_gpu:
+        torch.cuda.synchronize()                     # the broadcast ran on torch's stream; the library copies on its own
+    return ptdev.DeviceScene(slab=(buf.data_ptr(), buf.numel(), on_gpu))
 
 
 def broadcast_cameras(cams, device, dist, src=0):

@@ -3,8 +3,8 @@
     python -m pathtracing_amd.rm <scene> [-gi] [-rb] [--model omp|main] [--spp N] [--size N] [--views N] [--out DIR] [--split-rows]
     python -m torch.distributed.run --nproc-per-node N -m pathtracing_amd.rm <scene> -gi ...
 
-One process per GPU; rank 0 reads the scene and builds the kd-tree, the packed scene travels to the other ranks in one
-broadcast (RCCL when the backend is nccl), view v of scenes/paths/<scene>path.txt x 16 angles is rendered by rank
+One process per GPU; rank 0 reads the scene, builds the trees and uploads it, its device data travels to the other ranks
+in one broadcast (RCCL, GPU to GPU, when the backend is nccl), view v of scenes/paths/<scene>path.txt x 16 angles is rendered by rank
 v % N, and rank 0 collects the frames and writes <out>/<scene><v>.ppm.  Frames do not depend on N.
 With --split-rows every view is rendered by all N GPUs together instead, each the 8-row bands b with b % N == rank
 (the reference's own dealing of rows to its workers, mainOMP.cpp:169-174): same frames, shorter time to each frame.
@@ -52,7 +52,7 @@ def main(argv=None):
         dist.init_process_group(a.backend, **({"device_id": dev} if a.backend == "nccl" else {}))
     device.init(gpu)
 
-    blob = cams = None
+    ds = cams = None
     if rank == 0:
         sdir = os.path.join(a.root, "scenes", a.scene)
         hs = (host.HostScene.from_dir(sdir) if os.path.exists(os.path.join(sdir, "master.txt"))
@@ -64,11 +64,10 @@ def main(argv=None):
         cams = np.array([[*v.eye, v.angle, v.zoom] for v in views])
         if a.views >= 0:
             cams = cams[: a.views]
-        blob = device.scene_blob(hs.desc())
+        ds = device.DeviceScene(hs.desc())                    # the only rank that prepares the scene (fp32 tree included)
     if world > 1:
-        blob = multiview.broadcast_bytes(blob, xdev, dist)
+        ds = multiview.broadcast_scene(ds, xdev, dist)        # its device data, GPU to GPU
         cams = multiview.broadcast_cameras(cams, xdev, dist)
-    ds = device.DeviceScene(blob=blob)
     n = a.size
     frame = torch.empty(n * n * 3, dtype=torch.uint8, device=dev)
     opt = dict(gi=a.gi, rb=a.rb, model=device.MODEL_OMP if a.model == "omp" else device.MODEL_MAIN, spp=a.spp, size=n,

@@ -140,3 +140,81 @@ def test_bench_with_two_ranks_started_by_itself(cbox):
     # weak scaling: every rank renders the same cameras, so the job traced twice the rays
     rays = lambda j: j["value"] * 1e6 * j["ms_per_step"] * 1e-3 * j["steps"]
     assert abs(rays(two) / rays(one) - 2.0) < 0.02
+
+
+def test_view_loop_over_several_workers_gives_the_same_frames(tmp_path, cbox, monkeypatch):
+    """pt_render_views deals the views round-robin to one worker thread per device, each with its own copy of the scene.
+    On a one-GPU machine the workers all use that GPU (PT_TUNE_REPLICAS): three workers -- scene copied device to
+    device, and once more through an RCCL broadcast in a communicator of one rank, so that the RCCL calls run too --
+    write exactly the frames of one worker, with the same ray counts; `ptmain -rm --gpus all` on top of it writes the
+    same files as the plain loop."""
+    hs, ds = cbox
+    cams = host.views_from_path(os.path.join(ROOT, "scenes", "paths", "cboxpath.txt"), hs.camera()["zoom"])[:7]
+    kw = dict(gi=True, rb=True, spp=4, size=64, model=device.MODEL_OMP, gi_precision=device.GI_F32_FAST)
+    monkeypatch.delenv("PT_TUNE_REPLICAS", raising=False)
+    one, st1 = ds.render_views(cams, view0=0, view_stride=1, **kw)
+    for self_rccl in ("0", "1"):
+        monkeypatch.setenv("PT_TUNE_REPLICAS", "3")
+        monkeypatch.setenv("PT_TUNE_RCCL_SELF", self_rccl)
+        fresh = device.DeviceScene(hs.desc())                   # its copies are made on first use
+        three, st3 = fresh.render_views(cams, view0=0, view_stride=1, **kw)
+        again, _ = fresh.render_views(cams[:2], view0=0, view_stride=1, **kw)      # copies reused; fewer views than workers
+        fresh.close()
+        assert np.array_equal(one, three) and np.array_equal(one[:2], again)
+        for k in ("primary", "gi", "mirror", "shadow", "omp_retrace"):
+            assert st1[k] == st3[k], k
+    monkeypatch.delenv("PT_TUNE_RCCL_SELF")
+    a, b = tmp_path / "a", tmp_path / "b"
+    os.makedirs(a); os.makedirs(b)
+    monkeypatch.delenv("PT_TUNE_REPLICAS")
+    run(["cbox", "-rm", "-gi", "--views", "5", "--size", "48", "--spp", "2"], a)
+    env = dict(os.environ, PT_TUNE_REPLICAS="2")
+    r = subprocess.run([PTMAIN, "cbox", "-rm", "-gi", "--views", "5", "--size", "48", "--spp", "2", "--gpus", "all", "--out", str(b)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "World Size: 1" in r.stdout and r.stdout.count("Elapsed time:") == 5 and "views/s" in r.stdout
+    for v in range(5):
+        assert np.array_equal(read_ppm(a / f"cbox{v}.ppm"), read_ppm(b / f"cbox{v}.ppm")), v
+
+
+def test_scene_slab_round_trip(cbox):
+    """A scene's device data as one position-independent block: exported to host memory and to device memory, a scene
+    made from either renders the same frame as the original (nothing is prepared again: the fp32 tree travels inside);
+    a block with a damaged header is refused."""
+    import ctypes as C
+    hs, ds = cbox
+    c = hs.camera()
+    kw = dict(gi=True, spp=4, size=64, gi_precision=device.GI_F32_FAST)
+    want = ds.render(c["eye"], c["angle"], c["zoom"], **kw)
+    n = ds.slab_size()
+    assert n > 1 << 20
+    buf = np.zeros(n, np.uint8)
+    ds.slab_export(buf.ctypes.data, n, False)
+    from_host = device.DeviceScene(slab=(buf.ctypes.data, n, False))
+    got = from_host.render(c["eye"], c["angle"], c["zoom"], **kw)
+    assert np.array_equal(got["rgb"], want["rgb"]) and np.array_equal(got["tri"], want["tri"])
+    assert from_host.info() == ds.info()
+    # device to device, through the HIP runtime the library is linked to
+    hip = None
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            hip = C.CDLL(line.split()[-1])
+            break
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    d = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d), n) == 0
+    try:
+        ds.slab_export(d.value, n, True)
+        from_dev = device.DeviceScene(slab=(d.value, n, True))
+    finally:
+        hip.hipFree(d)
+    got = from_dev.render(c["eye"], c["angle"], c["zoom"], **kw)
+    assert np.array_equal(got["rgb"], want["rgb"])
+    from_dev.close(); from_host.close()
+    bad = buf.copy()
+    bad[100] ^= 0xFF
+    with pytest.raises(device.DeviceError, match="slab"):
+        device.DeviceScene(slab=(bad.ctypes.data, n, False))
+    with pytest.raises(device.DeviceError):
+        device.DeviceScene(slab=(buf.ctypes.data, n // 2, False))
