@@ -26,6 +26,11 @@
 #define FS_SLOTS 8                  // ring entries per lane in LDS (one of them is kept free)
 #define PT_REFILL_MIN 16             // idle lanes that trigger a refill
 #define PT_PASS_COUNT_WORDS 64       // per-pass counters, padded to a 256-byte line
+// Dynamic LDS asked for by a block of the shading kernel, which uses none of it: more than half of a CU's 160 KB, so
+// that a CU holds ONE shading block (16 waves) and the other half of its wave slots stays free for the ray generator
+// of the next pass, which is queued on the second stream and is bound by fp64 arithmetic while the shading kernel
+// streams memory.  Without it two shading blocks fill the CU and the two kernels run one after the other (+2.5 %).
+#define PT_SHADE_LDS_BYTES (81 * 1024)
 #define PT_QUEUE_CHUNK 64          // work items a wave takes from a queue head per atomicAdd
 
 // Queue append for a whole workgroup: ballot + prefix popcount inside each wave, a
@@ -583,10 +588,12 @@ int fast_alloc(FastBuffers Q[2], size_t pixels, int batch, PtAllocFn alloc, void
 // Launch parameters of the closest-hit kernel.  The defaults are what the
 // measurements in profiles/ were taken with; the PT_TUNE_* environment
 // variables exist for sweeps.
-struct TraceTune { int slots, refill, waves, chunk; };
+struct TraceTune { int slots, refill, waves, chunk, gen_lds, shade_lds; };
 static TraceTune trace_tune() {
     TraceTune t = [] {
-        TraceTune v{FS_SLOTS, PT_REFILL_MIN, PT_TRACE_WAVES, PT_QUEUE_CHUNK};
+        TraceTune v{FS_SLOTS, PT_REFILL_MIN, PT_TRACE_WAVES, PT_QUEUE_CHUNK, 0, PT_SHADE_LDS_BYTES};
+        if (const char *e = getenv("PT_TUNE_GEN_LDS")) { int k = atoi(e); if (k >= 0 && k <= 150000) v.gen_lds = k; }
+        if (const char *e = getenv("PT_TUNE_SHADE_LDS")) { int k = atoi(e); if (k >= 0 && k <= 150000) v.shade_lds = k; }
         if (const char *e = getenv("PT_TUNE_SLOTS")) { int k = atoi(e); if (k == 2 || k == 4 || k == 8 || k == 16 || k == 32) v.slots = k; }
         if (const char *e = getenv("PT_TUNE_REFILL")) { int k = atoi(e); if (k >= 1 && k <= 64) v.refill = k; }
         if (const char *e = getenv("PT_TUNE_CHUNK")) { int k = atoi(e); if (k >= 16 && k <= 65536) v.chunk = k; }
@@ -630,7 +637,7 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         // traversal has ended, so that it runs beside the shading instead, was slower.)
         FQ(hipStreamWaitEvent(s_gen, pass >= 2 ? events[4 * (pass - 2) + 3] : view_ready, 0));
         FQ(hipMemsetAsync(Q.counts, 0, (PT_PASS_COUNT_WORDS + 2 * PT_HEAD_WORDS) * sizeof(uint32_t), s_gen));
-        hipLaunchKernelGGL(k_gi_gen, dim3((unsigned)((tthreads / 64) * groups)), dim3(1024), 0, s_gen, S, V, F, Q, s0, nb, groups);
+        hipLaunchKernelGGL(k_gi_gen, dim3((unsigned)((tthreads / 64) * groups)), dim3(1024), (size_t)tune.gen_lds, s_gen, S, V, F, Q, s0, nb, groups);
         FQ(hipEventRecord(events[4 * pass], s_gen));
         return PT_OK;
     };
@@ -654,10 +661,10 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
             hipLaunchKernelGGL(k_trace_closest<false>, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
         FQ(hipEventRecord(events[4 * pass + 2], s));
         if (V.model == PT_MODEL_MAIN) {
-            hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(sblocks), dim3(PT_APPEND_BLOCK), 0, s, S, Q);
+            hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(sblocks), dim3(PT_APPEND_BLOCK), (size_t)tune.shade_lds, s, S, Q);
             hipLaunchKernelGGL(k_shadow_gi, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
         } else {
-            hipLaunchKernelGGL(k_shade_gi<PT_MODEL_OMP>, dim3(sblocks), dim3(PT_APPEND_BLOCK), 0, s, S, Q);
+            hipLaunchKernelGGL(k_shade_gi<PT_MODEL_OMP>, dim3(sblocks), dim3(PT_APPEND_BLOCK), (size_t)tune.shade_lds, s, S, Q);
         }
         hipLaunchKernelGGL(k_gi_sum, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, F, Q, V.size, nb, s0 == 0);
         FQ(hipEventRecord(events[4 * pass + 3], s));
