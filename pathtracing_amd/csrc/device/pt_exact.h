@@ -148,27 +148,11 @@ PT_DEV bool search_node_uniform(const DevScene &S, int node0, int first0, int co
     return found;
 }
 
-// COHERENT: the rays of the wave are neighbours (sub-rays of a bundle, pixels of a tile, their mirror rays) and are in
-// one node, or a few, at any time: the distinct nodes are taken one after the other, each through the scalar unit
-// (one request per wave instead of one per lane, and no per-lane copy of the triangle in registers).  Otherwise
-// (incoherent rays) the scalar path is taken only when every lane is in the same node, and each lane loads for itself.
-template <bool COHERENT>
+// The rays of a wave are neighbours (sub-rays of a bundle, pixels of a tile) and are often all in one node: then the
+// node's list comes through the scalar unit, one request per wave; otherwise each lane loads for itself.  (Taking the
+// distinct nodes of a wave one after the other through the scalar unit instead was slower on every scene: 1.86 against
+// 1.60 ms for the bundles of an atrium view.)
 PT_DEV bool search_node(const DevScene &S, int node, const NodeA &na, const RayD &ray, HitD &h) {
-    if (COHERENT) {
-        bool found = false, pending = true;
-        for (;;) {
-            if (pending) {
-                const int node0 = __builtin_amdgcn_readfirstlane(node);
-                if (node == node0) {
-                    const int first0 = __builtin_amdgcn_readfirstlane(na.first), count0 = __builtin_amdgcn_readfirstlane(na.count);
-                    found = search_node_uniform(S, node0, first0, count0, ray, h);
-                    pending = false;
-                }
-            }
-            if (!__any(pending)) break;
-        }
-        return found;
-    }
     const int node0 = __builtin_amdgcn_readfirstlane(node);
     if (__all(node == node0)) {
         // every active lane is in this node: its list comes through the scalar unit, once for the wave
@@ -223,7 +207,7 @@ struct SearchNote {
 };
 
 // search(), util/kdtree.cpp:216-257.  h.tmin is the in/out bound.  NOTED: also fills *note.
-template <bool NOTED, bool COHERENT>
+template <bool NOTED>
 PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, SearchNote *note, StackD &st) {
     double ent, ext;
     if (NOTED) { note->far_max = -DBL_MAX; note->stack_min = DBL_MAX; }
@@ -235,7 +219,7 @@ PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, SearchNote
         if (ent >= h.tmin) break;                   // util/kdtree.cpp:229-231: ends the whole search
         NodeA na = fetch_node(S, curr);
         while (na.axis >= 0) {
-            if (na.count > 0) found |= search_node<COHERENT>(S, curr, na, ray, h);
+            if (na.count > 0) found |= search_node(S, curr, na, ray, h);
             double s = na.split;
             int a = na.axis;
             double da = dget(ray.dir, a), sa = dget(ray.src, a);
@@ -255,15 +239,14 @@ PT_DEV bool search_ref_t(const DevScene &S, const RayD &ray, HitD &h, SearchNote
             }
             na = fetch_node(S, curr);
         }
-        if (na.count > 0 && search_node<COHERENT>(S, curr, na, ray, h)) { at_leaf = true; break; }
+        if (na.count > 0 && search_node(S, curr, na, ray, h)) { at_leaf = true; break; }
         if (st.size() == 0) break;
         st.pop(curr, ent, ext);
     }
     if (NOTED) note->stack_min = st.min_ent();
     return at_leaf || found;
 }
-template <bool COHERENT>
-PT_DEV bool search_ref(const DevScene &S, const RayD &ray, HitD &h, StackD &st) { return search_ref_t<false, COHERENT>(S, ray, h, nullptr, st); }
+PT_DEV bool search_ref(const DevScene &S, const RayD &ray, HitD &h, StackD &st) { return search_ref_t<false>(S, ray, h, nullptr, st); }
 
 // ---- shading ------------------------------------------------------------------
 
@@ -360,12 +343,12 @@ struct CastHit { HitD h; D3 nrm, txt, hit, direct, alb; int reft; };
 
 // The first part of castRay, main.cpp:41-66 (MODEL == PT_MODEL_MAIN) / mainOMP.cpp:37-63 (PT_MODEL_OMP):
 // false on a miss (c.h then holds the search's record).
-template <int MODEL, bool COHERENT>
+template <int MODEL>
 PT_DEV bool cast_hit(const DevScene &S, const RayD &ray, StackD &st, RayCounts &rc, CastHit &c) {
     HitD &h = c.h;
     h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
     SearchNote note;
-    bool ok = MODEL == PT_MODEL_OMP ? search_ref_t<true, COHERENT>(S, ray, h, &note, st) : search_ref<COHERENT>(S, ray, h, st);
+    bool ok = MODEL == PT_MODEL_OMP ? search_ref_t<true>(S, ray, h, &note, st) : search_ref(S, ray, h, st);
     if (!ok) return false;
     c.nrm = surface_normal(S, h.tri, h.u, h.v);
     c.hit = dadd(dadd(ray.src, dscale(h.tmin, ray.dir)), dscale(0.0001, c.nrm));
@@ -383,10 +366,10 @@ PT_DEV bool cast_hit(const DevScene &S, const RayD &ray, StackD &st, RayCounts &
         if (MODEL == PT_MODEL_MAIN) {                        // main.cpp:62-63: a real shadow ray
             RayD lray = make_ray(c.hit, ldir);
             HitD sh; sh.tmin = dis; sh.tri = -1; sh.u = 0; sh.v = 0;
-            vis = !search_ref<COHERENT>(S, lray, sh, st);
+            vis = !search_ref(S, lray, sh, st);
             rc.n[RC_SHADOW]++;
         } else {                                             // mainOMP.cpp:60: re-traces `ray` bounded by its own hit
-            if (!retrace_clear) retrace_clear = !search_ref<COHERENT>(S, ray, h, st);
+            if (!retrace_clear) retrace_clear = !search_ref(S, ray, h, st);
             vis = retrace_clear;
             rc.n[RC_RETRACE]++;
         }
@@ -411,10 +394,10 @@ PT_DEV D3 cast_value(const CastHit &c, int depth, D3 ref) {
 }
 
 // castRay at depth != 0 (a GI sample ray, or the mirror bounce of a primary hit): no G-buffer, no further bounce.
-template <int MODEL, bool COHERENT>
+template <int MODEL>
 PT_DEV D3 cast_secondary(const DevScene &S, const RayD &ray, int depth, StackD &st, RayCounts &rc) {
     CastHit c;
-    if (!cast_hit<MODEL, COHERENT>(S, ray, st, rc, c)) return d3(0, 0, 0);
+    if (!cast_hit<MODEL>(S, ray, st, rc, c)) return d3(0, 0, 0);
     return cast_value<MODEL>(c, depth, d3(0, 0, 0));
 }
 

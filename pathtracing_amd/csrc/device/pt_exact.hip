@@ -36,7 +36,7 @@ PT_DEV void flush_counts(const RayCounts &rc, unsigned long long *counters) {
 // hundredth of a pixel, so they walk the tree together.  The sub-ray results are folded
 // into the frame buffers by k_primary_combine in the reference's order.
 template <int MODEL>
-__global__ void __launch_bounds__(64) k_primary_exact(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B, uint32_t nblocks) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_primary_exact(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B, uint32_t nblocks) {
     extern __shared__ double stack_lds[];
     StackD st = make_stack(S, stack_lds);
     RayCounts rc;
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(64) k_primary_exact(DevScene S, ViewParams V, 
         CastHit c;
         D3 paint;
         int mirror = 0;
-        if (!cast_hit<MODEL, true>(S, ray, st, rc, c)) {
+        if (!cast_hit<MODEL>(S, ray, st, rc, c)) {
             const D3 zero = d3(0, 0, 0);
             dstore(B.g + 9 * slot, zero); dstore(B.g + 9 * slot + 3, zero); dstore(B.g + 9 * slot + 6, d3(-99999, -99999, -99999));
             B.found[slot] = 0; B.tri[slot] = -1;
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(64) k_mirror_exact(DevScene S, ViewParams V, F
         if (!B.mirror[slot]) continue;
         const RayD rray = make_ray(dload(B.g + 9 * slot + 6), dload(B.mdir + 3 * slot));
         D3 ref = d3(0, 0, 0);
-        ref = dadd(ref, cast_secondary<MODEL, true>(S, rray, MODEL == PT_MODEL_MAIN ? 1 : -1, st, rc));
+        ref = dadd(ref, cast_secondary<MODEL>(S, rray, MODEL == PT_MODEL_MAIN ? 1 : -1, st, rc));
         dstore(B.paint + 3 * slot, dadd(dload(B.paint + 3 * slot), dscale(0.4, ref)));
     }
     flush_counts(rc, F.counters);
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(64) k_gi_exact(DevScene S, ViewParams V, Frame
                           sm.x * Nb.z + sm.y * nrm.z + sm.z * Nt.z);
             RayD iray = make_ray(hit, world);
             rc.n[RC_GI]++;
-            out = dscale(r1, cast_secondary<MODEL, false>(S, iray, -1, st, rc));
+            out = dscale(r1, cast_secondary<MODEL>(S, iray, -1, st, rc));
         }
         dstore(F.contrib + ((size_t)sl * P + p) * 3, out);
     }
@@ -250,13 +250,13 @@ __global__ void __launch_bounds__(64) k_trace_exact(DevScene S, size_t n, const 
         bool ok;
         if (research) {
             SearchNote note;
-            ok = search_ref_t<true, false>(S, ray, h, &note, st);
+            ok = search_ref_t<true>(S, ray, h, &note, st);
             if (ok) {
                 h.tri = -1; h.u = 0; h.v = 0;                 // the bound stays: the first hit's distance
-                ok = note.may_find_closer(h.tmin) && search_ref<false>(S, ray, h, st);
+                ok = note.may_find_closer(h.tmin) && search_ref(S, ray, h, st);
             }
         } else {
-            ok = search_ref<false>(S, ray, h, st);
+            ok = search_ref(S, ray, h, st);
         }
         found[k] = ok; tri[k] = h.tri; t[k] = h.tmin; u[k] = h.u; v[k] = h.v;
     }
