@@ -218,3 +218,14 @@ def test_scene_slab_round_trip(cbox):
         device.DeviceScene(slab=(bad.ctypes.data, n, False))
     with pytest.raises(device.DeviceError):
         device.DeviceScene(slab=(buf.ctypes.data, n // 2, False))
+
+
+def test_nccl_backend_exchanges_on_one_rank():
+    """The RCCL side of the one-process-per-GPU job (scene broadcast from device memory, camera broadcast, frame gather,
+    reductions) on a process group of one rank, plus the receiving side of the scene broadcast done by hand on the
+    same GPU.  Two ranks cannot share a GPU under RCCL, so this is as far as a one-GPU machine goes."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_one_rank.py"), str(free_port())], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "nccl one-rank exchanges ok" in r.stdout, r.stdout + r.stderr
