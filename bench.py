@@ -136,8 +136,14 @@ def physical_roofline(workload, n_node, n_tri, kernel_mrays, ms_launch, rays_lau
         clocks = h1 / rates["l1"] + (1 - h1) * h2 / rates["l2"] + (1 - h1) * (1 - h2) / rates["beyond"]
         req = phys.get("hw_requests_per_ray", phys["lane_requests_per_ray"])
         ceiling = 256 * 2.4e9 / (req * clocks) / 1e6           # the micro-benchmark normalises by the same 256 CUs x 2.4 GHz
-        phys.update(clocks_per_request=round(clocks, 3), ceiling_mrays_per_s=round(ceiling, 1),
-                    achieved_mrays_per_s=round(kernel_mrays, 1), frac=round(kernel_mrays / ceiling, 4))
+        phys.update(clocks_per_request=round(clocks, 3), request_ceiling_mrays_per_s=round(ceiling, 1),
+                    achieved_mrays_per_s=round(kernel_mrays, 1), request_model_frac=round(kernel_mrays / ceiling, 4))
+    # the fraction that counts: how busy the busiest of the two units that bound the kernel is (1 = that unit never idles)
+    units = {k: phys[k] for k in ("ta_busy", "valu_issue") if k in phys}
+    if units:
+        top = max(units, key=units.get)
+        phys["frac"] = units[top]
+        phys["frac_of"] = {"ta_busy": "L1 address path (TA) busy cycles / cycles", "valu_issue": "VALU issue cycles / SIMD cycles"}[top]
     return phys
 
 
@@ -386,6 +392,7 @@ def main():
             r = orc.render(row0=step_rows // 2, row_step=step_rows, nrows_limit=rows, **okw)
             crays = sum(v["searches"] for k, v in r["counts"].items() if k != "omp_retrace")
             cpu = {"value": round(crays / r["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "host_cpus_visible": os.cpu_count(),       # the whole machine; a one-GPU job's share of it is 16 threads
                    "sample": f"{rows} of 512 image rows (every {step_rows}th) of one view at the same spp: "
                              f"{crays} rays in {r['seconds']:.1f} s on {cores} threads"}
 

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <exception>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -92,6 +93,7 @@ struct PtScene {
     uint32_t n_tri = 0, n_mesh = 0;
     std::vector<int32_t> tri_mesh, tri_local;   // host copies for (mesh, tri) reporting
     std::vector<PtScene *> replicas;            // copies of this scene on the other initialised devices (pt_render_views)
+    std::mutex busy;                            // calls on one scene are serialised: it has one workspace, one stream pair
 };
 
 namespace {
@@ -509,6 +511,7 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     int rc = check_options(o, &size, &N);
     if (rc) return rc;
     if (!cam) return fail(PT_ERR_INVALID, "camera is null");
+    HIPCHK(hipSetDevice(sc->device));          // the current device belongs to the calling thread, not to the process
     const bool fast = o->gi && o->gi_precision == PT_GI_F32_FAST;
     size_t P = (size_t)size * size;
     // samples per GI pass: bounded so that per-pass buffers stay at a few hundred MB
@@ -915,6 +918,7 @@ int pt_scene_upload_blob(const void *blob, size_t bytes, PtScene **out) { return
 
 int pt_render_view(PtScene *sc, const PtCamera *cam, const PtOptions *opt, uint8_t *bgr_out, PtAov *aov, PtStats *stats) { return guarded([&]() -> int {
     if (!sc) return fail(PT_ERR_INVALID, "scene is null");
+    std::lock_guard<std::mutex> lock(sc->busy);
     auto t0 = std::chrono::steady_clock::now();
     float gi_ms; uint64_t gi_l;
     int rc = render_on_device(sc, cam, opt, stats, &gi_ms, &gi_l);
@@ -944,6 +948,7 @@ int pt_render_view(PtScene *sc, const PtCamera *cam, const PtOptions *opt, uint8
 
 int pt_render_view_device(PtScene *sc, const PtCamera *cam, const PtOptions *opt, void *d_bgr, PtStats *stats) { return guarded([&]() -> int {
     if (!sc || !d_bgr) return fail(PT_ERR_INVALID, "scene or output pointer is null");
+    std::lock_guard<std::mutex> lock(sc->busy);
     auto t0 = std::chrono::steady_clock::now();
     float gi_ms; uint64_t gi_l;
     int rc = render_on_device(sc, cam, opt, stats, &gi_ms, &gi_l);
@@ -961,6 +966,7 @@ int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0,
     int size, N;
     int rc = check_options(opt, &size, &N);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lock(sc->busy);
     auto t0 = std::chrono::steady_clock::now();
     const size_t frame_bytes = (size_t)size * size * 3;
     // One worker per device: worker w renders the views i with i % workers == w on its copy of the scene and copies
@@ -1041,6 +1047,8 @@ int pt_trace(PtScene *sc, size_t n, const double *src, const double *dir, const 
     if (n == 0) return PT_OK;
     if (!src || !dir || !tmin_in || !found || !mesh || !tri || !t || !u || !v) return fail(PT_ERR_INVALID, "pt_trace: null array");
     if (n > ((size_t)1 << 28)) return fail(PT_ERR_LIMIT, "pt_trace: more than 2^28 rays in one call");
+    std::lock_guard<std::mutex> lock(sc->busy);
+    HIPCHK(hipSetDevice(sc->device));
     double *d_src = nullptr, *d_dir = nullptr, *d_tmin = nullptr, *d_t = nullptr, *d_u = nullptr, *d_v = nullptr;
     int32_t *d_found = nullptr, *d_tri = nullptr;
     std::vector<void *> tmp;
@@ -1091,7 +1099,9 @@ int pt_trace_device(PtScene *sc, size_t n, const double *d_src, const double *d_
     if (n > PT_STATIC_MAX_RAYS) return fail(PT_ERR_LIMIT, "pt_trace_device: more than 2^24 rays in one call");
     if (sc->S.ovf_depth > PT_STATIC_DEPTH)
         return fail(PT_ERR_LIMIT, "pt_trace_device: the scene's fp32 tree is deeper than the fixed scratch stack (62 levels)");
-    int rc = fast_trace_static(sc->S, g_device, n, d_src, d_dir, d_tmin_in, d_found, d_mesh, d_tri, d_t, d_u, d_v, sc->stream);
+    std::lock_guard<std::mutex> lock(sc->busy);       // one scene, one stream; the fixed scratch array is per GPU (see the header)
+    HIPCHK(hipSetDevice(sc->device));
+    int rc = fast_trace_static(sc->S, sc->device, n, d_src, d_dir, d_tmin_in, d_found, d_mesh, d_tri, d_t, d_u, d_v, sc->stream);
     if (rc == PT_ERR_HIP) return fail(rc, std::string("pt_trace_device: ") + hipGetErrorString(hipGetLastError()));
     if (rc) return fail(rc, "pt_trace_device: no scratch address for this device (pt_init), or a size limit");
     return check_limits(sc, "pt_trace_device");

@@ -18,9 +18,22 @@ def test_pmc_traffic_reads_the_committed_counter_summaries():
     assert abs(half - bench.pmc_traffic("atrium", 16777216)[0] / 2) < 0.02
 
 
+def test_counter_collections_carry_the_kernel_source_digest():
+    """The newest collection per workload records the digest of the kernel sources it was taken with; bench.py flags
+    traffic and hit rates as stale when the sources have changed since."""
+    import bench
+    m = bench.pmc_means("atrium")
+    assert m["source"].startswith("profiles/r02/") and m["kernel_source_hash"] and m["rays_per_launch"] > 6e7
+    assert len(bench.kernel_source_hash()) == 16
+    p = bench.physical_roofline("atrium", 63.6, 15.25, 4450.0, 15.0, 67108800)
+    assert p["counters_stale"] == (m["kernel_source_hash"] != bench.kernel_source_hash())
+    assert 0.5 < p["frac"] <= 1.0 and p["frac"] == max(p["ta_busy"], p["valu_issue"])
+    assert 0.05 < p["hbm_side_frac_of_peak"] < 0.5          # the kernel is far from HBM-bound
+
+
 def test_committed_bench_lines_have_the_contract_fields():
     for name in ("bench_default_atrium.json", "bench_default_car.json"):
-        j = json.load(open(os.path.join(ROOT, "profiles", "r01", name)))
+        j = json.load(open(os.path.join(ROOT, "profiles", "r02", name)))
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                   "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
             assert k in j, (name, k)
@@ -29,7 +42,7 @@ def test_committed_bench_lines_have_the_contract_fields():
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
             assert k in r, (name, k)
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-        assert r["traffic"] is not None
+        assert r["traffic"] is not None and r["bound"].startswith("hbm") and r["physical"]["limiter"]
         c = j["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
 

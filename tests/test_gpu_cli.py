@@ -229,3 +229,30 @@ def test_nccl_backend_exchanges_on_one_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_one_rank.py"), str(free_port())], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "nccl one-rank exchanges ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_two_host_threads_on_one_scene(cbox):
+    """Calls on one scene from two host threads are serialised by the library (one workspace, one stream pair per scene):
+    both threads get exactly the frames a single thread gets."""
+    import threading
+    hs, ds = cbox
+    c = hs.camera()
+    kw = dict(gi=True, spp=8, size=96, model=device.MODEL_OMP, gi_precision=device.GI_F32_FAST, aov=False)
+    want = [ds.render(c["eye"], c["angle"] + 0.3 * k, c["zoom"], view=k, **kw)["bgr"] for k in range(6)]
+    got, errors = {}, []
+
+    def worker(ks):
+        try:
+            for k in ks:
+                got[k] = ds.render(c["eye"], c["angle"] + 0.3 * k, c["zoom"], view=k, **kw)["bgr"]
+        except Exception as e:                                  # noqa: BLE001 -- reported by the assertion below
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(range(w, 6, 2),)) for w in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(6):
+        assert np.array_equal(got[k], want[k]), k

@@ -200,9 +200,10 @@ def test_second_search_rule_equals_a_second_search(gpu_scenes, oracle_scenes, na
 
 @pytest.mark.parametrize("name", ["cbox", "car", "pine", "terrace"])
 def test_fast_trace_against_brute_force(gpu_scenes, oracle_scenes, name):
-    """pt_trace mode 1 (fp32 kd traversal, the GI fast path) finds the true nearest hit:
-    same triangle as an fp64 brute force wherever the two nearest candidates are not
-    within fp32 noise of each other, t within 1e-5 relative."""
+    """pt_trace mode 1 (fp32 kd traversal, the GI fast path) finds the true nearest hit: same triangle as an fp64 brute
+    force on at least 99.95 % of the rays (the rest: two candidates within fp32 noise of each other), found / missed
+    agreeing on all but 1 in 10 000, and the fp32 hit distance within 1e-6 relative at the median and 3e-4 at the
+    99.9th percentile (grazing hits cancel).  The 1e-5 contract on t is about primary hits, which are fp64 and exact."""
     s = oracle_scenes(name)
     src, d = random_rays(20000, 11, s.root_box())
     tmin = np.full(len(src), device.FLT_MAX)
