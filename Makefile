@@ -35,7 +35,7 @@ $(PKG)/libptamd.so: $(DEVOBJ)
 	$(HIPCC) --offload-arch=gfx950 -shared -o $@ $(DEVOBJ)
 
 $(PKG)/ptmain: $(PKG)/csrc/cli/ptmain.cpp $(PKG)/libpthost.so $(PKG)/libptamd.so
-	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG) -lpthost -lptamd -Wl,-rpath,'$$ORIGIN' -L$(ROCM)/lib -Wl,-rpath,$(ROCM)/lib
+	$(CXX) $(CXXFLAGS) -o $@ $< -pthread -L$(PKG) -lpthost -lptamd -Wl,-rpath,'$$ORIGIN' -L$(ROCM)/lib -Wl,-rpath,$(ROCM)/lib
 
 # load-rate micro-benchmark that bench.py runs beside its timings (the physical ceiling of the traversal kernel)
 tools/ta_rate: tools/ta_rate.hip

@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pathtracing_amd.h"
@@ -141,21 +142,33 @@ int main(int argc, char **argv) {
         if (dataset.empty() && all_gpus) {
             // the view loop inside the library: batches of views, sharded over the GPUs, frames written between batches
             const size_t batch = 8 * (size_t)pt_device_count();
-            std::vector<uint8_t> frames(batch * frame.size());
+            std::vector<uint8_t> frames[2] = {std::vector<uint8_t>(batch * frame.size()), std::vector<uint8_t>(batch * frame.size())};
+            std::thread writer;                                 // writes the files of one batch while the next one renders
+            int write_failed = 0;
             PtStats st{};
             auto t0 = std::chrono::high_resolution_clock::now();
-            for (size_t v0 = 0; v0 < total; v0 += batch) {
+            size_t turn = 0;
+            for (size_t v0 = 0; v0 < total; v0 += batch, turn ^= 1) {
                 const size_t nb = total - v0 < batch ? total - v0 : batch;
                 auto tb = std::chrono::high_resolution_clock::now();
-                if (pt_render_views(ds, cams.data() + v0, nb, (uint32_t)v0, 1, &opt, frames.data(), &st)) return die("pt_render_views", pt_last_error());
-                std::chrono::duration<double> el = std::chrono::high_resolution_clock::now() - tb;
-                for (size_t k = 0; k < nb; k++) {
-                    char name[64];
-                    std::snprintf(name, sizeof name, "/%s%zu.ppm", scene.c_str(), v0 + k);
-                    std::printf("Elapsed time: %g s\n", el.count() / (double)nb);
-                    if (pth_write_ppm((out + name).c_str(), frames.data() + k * frame.size(), n, n)) return die("write", pth_last_error());
+                uint8_t *buf = frames[turn].data();
+                if (pt_render_views(ds, cams.data() + v0, nb, (uint32_t)v0, 1, &opt, buf, &st)) {
+                    if (writer.joinable()) writer.join();
+                    return die("pt_render_views", pt_last_error());
                 }
+                std::chrono::duration<double> el = std::chrono::high_resolution_clock::now() - tb;
+                for (size_t k = 0; k < nb; k++) std::printf("Elapsed time: %g s\n", el.count() / (double)nb);
+                if (writer.joinable()) writer.join();          // the other buffer is free again after this
+                writer = std::thread([&, buf, v0, nb] {
+                    for (size_t k = 0; k < nb; k++) {
+                        char name[64];
+                        std::snprintf(name, sizeof name, "/%s%zu.ppm", scene.c_str(), v0 + k);
+                        if (pth_write_ppm((out + name).c_str(), buf + k * frame.size(), n, n)) write_failed = 1;
+                    }
+                });
             }
+            if (writer.joinable()) writer.join();
+            if (write_failed) return die("write", "a frame file could not be written");
             std::chrono::duration<double> el = std::chrono::high_resolution_clock::now() - t0;
             const unsigned long long rays = st.primary + st.shadow + st.mirror + st.gi;
             std::printf("%zu views on %d GPU(s) in %.3f s: %.2f views/s, %.1f Mrays/s\n", total, pt_device_count(), el.count(),

@@ -32,6 +32,7 @@ def main(argv=None):
     ap.add_argument("--root", default=os.getcwd(), help="directory that holds scenes/")
     ap.add_argument("--split-rows", action="store_true", help="all GPUs share every view (bands of 8 rows) instead of one view each")
     ap.add_argument("--exact-gi", action="store_true", help="fp64 GI rays (bit-identical to the CPU oracle)")
+    ap.add_argument("--writers", type=int, default=4, help="threads of rank 0 that write the frame files")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: every rank on GPU 0, exchanges staged through host memory (rehearsal on a one-GPU box)")
     a = ap.parse_args(argv)
@@ -80,9 +81,10 @@ def main(argv=None):
         return frame if a.backend == "nccl" else frame.cpu()
 
     t_last = [time.perf_counter()]
-    # Files are written by a second thread, so that the GPU renders the next view meanwhile (the render call and the
-    # file write both release the interpreter lock).
-    pending = queue.Queue(maxsize=8)
+    # Files are written by a few more threads, so that the GPU renders the next views meanwhile (the render call and the
+    # file write both release the interpreter lock).  Eight GPUs at 300 views/s each hand rank 0 about 2 GB/s of frames:
+    # more than one thread copies into the page cache.
+    pending = queue.Queue(maxsize=64)
     failed = []
 
     def writer():
@@ -101,19 +103,22 @@ def main(argv=None):
         t_last[0] = now
         pending.put((v, pixels))
 
-    wthread = None
+    wthreads = []
     if rank == 0:
         os.makedirs(a.out, exist_ok=True)
-        wthread = threading.Thread(target=writer, daemon=True)
-        wthread.start()
+        wthreads = [threading.Thread(target=writer, daemon=True) for _ in range(max(1, a.writers))]
+        for t in wthreads:
+            t.start()
     t0 = time.perf_counter()
     if a.split_rows:
         multiview.run_split_views(render, len(cams), n, xdev, dist if world > 1 else None, on_frame if rank == 0 else None)
     else:
         multiview.run_views(render, len(cams), frame.numel(), xdev, dist if world > 1 else None, on_frame if rank == 0 else None)
-    if wthread is not None:
-        pending.put(None)
-        wthread.join()
+    if wthreads:
+        for _ in wthreads:
+            pending.put(None)
+        for t in wthreads:
+            t.join()
         if failed:
             sys.exit(f"writing frames failed: {failed[0]}")
     if world > 1:
