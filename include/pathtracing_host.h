@@ -65,9 +65,12 @@ int pth_camera_step(double eye[3], double *angle, double step, double astep, int
    BGR8.  Call with bgr == NULL to get the size; `capacity` is the size of `bgr` in bytes. */
 int pth_decode_image(const char *path, int *rows, int *cols, uint8_t *bgr, size_t capacity);
 
-/* Image output (the reference only shows frames with cv::imshow). */
+/* Image output.  The reference shows frames with cv::imshow and notes "change to imwrite ... for en masse renderings"
+   (mainOMP.cpp:242); its data sets under ml/data/ are such JPEG files.  pth_write_jpeg writes a baseline JPEG
+   (YCbCr 4:2:0, standard tables; quality 1..100, 95 is what cv::imwrite uses by default). */
 int pth_write_ppm(const char *path, const uint8_t *bgr, int rows, int cols);
 int pth_write_bmp(const char *path, const uint8_t *bgr, int rows, int cols);
+int pth_write_jpeg(const char *path, const uint8_t *bgr, int rows, int cols, int quality);
 
 /* Deterministic procedural scene of a given triangle budget, standing in for
    meshes that are not available (writes meshes/lights/camera into a scene). */

@@ -20,7 +20,8 @@
 // three images the reference's denoiser is trained on, DIR/<SCENE>/<SCENE>4ssp,
 // <SCENE>4096ssp and <SCENE>dif, named <scene><view>.ppm: 4 spp, 4096 spp and the
 // pass without -gi of mainOMP.cpp:263-270; --noisy-spp / --converged-spp change
-// the two counts).
+// the two counts), --format ppm|jpg (frame files; jpg is what the reference's data
+// sets are, written with cv::imwrite's default quality 95).
 #include <cctype>
 #include <iostream>
 #include <sstream>
@@ -46,7 +47,7 @@ static int die(const char *what, const char *msg) {
 
 int main(int argc, char **argv) {
     bool gi = false, rb = false, rm = false, exact_gi = false, from_stdin = false, all_gpus = false;
-    std::string scene, model_s, out = ".", keys, dataset;
+    std::string scene, model_s, out = ".", keys, dataset, format = "ppm";
     int spp = 0, size = 0, max_views = -1, dev = 0, noisy_spp = 4, converged_spp = 4096;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -73,6 +74,10 @@ int main(int argc, char **argv) {
         else if (a == "--exact-gi") exact_gi = true;
         else if (a == "--stdin") from_stdin = true;
         else if (a == "--dataset") dataset = val("--dataset");
+        else if (a == "--format") {
+            format = val("--format");
+            if (format != "ppm" && format != "jpg") { std::fprintf(stderr, "ptmain: --format must be ppm or jpg\n"); return 2; }
+        }
         else if (a == "--noisy-spp") noisy_spp = std::atoi(val("--noisy-spp"));
         else if (a == "--converged-spp") converged_spp = std::atoi(val("--converged-spp"));
         else if (!a.empty() && a[0] != '-') scene = a;
@@ -109,6 +114,10 @@ int main(int argc, char **argv) {
     const int n = size ? size : 512;
     std::vector<uint8_t> frame((size_t)n * n * 3);
 
+    const std::string ext = "." + format;
+    auto write_frame = [&](const std::string &file, const uint8_t *bgr) -> int {
+        return format == "jpg" ? pth_write_jpeg(file.c_str(), bgr, n, n, 95) : pth_write_ppm(file.c_str(), bgr, n, n);
+    };
     auto render_one = [&](const PtCamera &cam, uint32_t view, const std::string &file) -> int {
         opt.view = view;
         PtStats st{};
@@ -120,7 +129,7 @@ int main(int argc, char **argv) {
         std::printf("  rays: primary %llu shadow %llu mirror %llu gi %llu  (%.1f Mrays/s) -> %s\n",
                     (unsigned long long)st.primary, (unsigned long long)st.shadow, (unsigned long long)st.mirror,
                     (unsigned long long)st.gi, rays / el.count() * 1e-6, file.c_str());
-        if (pth_write_ppm(file.c_str(), frame.data(), n, n)) return die("write", pth_last_error());
+        if (write_frame(file, frame.data())) return die("write", pth_last_error());
         return 0;
     };
 
@@ -162,8 +171,8 @@ int main(int argc, char **argv) {
                 writer = std::thread([&, buf, v0, nb] {
                     for (size_t k = 0; k < nb; k++) {
                         char name[64];
-                        std::snprintf(name, sizeof name, "/%s%zu.ppm", scene.c_str(), v0 + k);
-                        if (pth_write_ppm((out + name).c_str(), buf + k * frame.size(), n, n)) write_failed = 1;
+                        std::snprintf(name, sizeof name, "/%s%zu", scene.c_str(), v0 + k);
+                        if (write_frame(out + name + ext, buf + k * frame.size())) write_failed = 1;
                     }
                 });
             }
@@ -177,7 +186,7 @@ int main(int argc, char **argv) {
         }
         for (size_t v = 0; v < total; v++) {
             char name[64];
-            std::snprintf(name, sizeof name, "/%s%zu.ppm", scene.c_str(), v);
+            std::snprintf(name, sizeof name, "/%s%zu%s", scene.c_str(), v, ext.c_str());
             if (dataset.empty()) {
                 if (render_one(cams[v], (uint32_t)v, out + name)) return 1;
                 continue;
@@ -192,11 +201,11 @@ int main(int argc, char **argv) {
         }
     } else {                                                    // simulate(), main.cpp:152-189
         PtCamera cam{{cam7[0], cam7[1], cam7[2]}, cam7[5], cam7[6]};
-        if (render_one(cam, 0, out + "/" + scene + ".ppm")) return 1;
+        if (render_one(cam, 0, out + "/" + scene + ext)) return 1;
         for (size_t k = 0; k < keys.size(); k++) {
             if (pth_camera_step(cam.eye, &cam.angle, cam7[3], cam7[4], keys[k])) return die("--keys", pth_last_error());
             char name[64];
-            std::snprintf(name, sizeof name, "/%s_step%zu.ppm", scene.c_str(), k + 1);
+            std::snprintf(name, sizeof name, "/%s_step%zu%s", scene.c_str(), k + 1, ext.c_str());
             if (render_one(cam, 0, out + name)) return 1;
         }
         if (from_stdin) {
@@ -215,7 +224,7 @@ int main(int argc, char **argv) {
                     return die("--stdin", ("unknown command '" + line + "'").c_str());
                 }
                 char name[64];
-                std::snprintf(name, sizeof name, "/%s_frame%zu.ppm", scene.c_str(), k);
+                std::snprintf(name, sizeof name, "/%s_frame%zu%s", scene.c_str(), k, ext.c_str());
                 if (render_one(cam, 0, out + name)) return 1;
                 std::fflush(stdout);
             }

@@ -7,6 +7,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -100,11 +101,14 @@ namespace {
 
 std::vector<int> g_devices;           // the devices pt_init selected; g_device is the first of them
 
-uint64_t header_check(SlabHeader h) {
-    h.check = 0;
+// FNV-1a over the header's bytes as they lie in memory (padding included: a header is only ever moved with memcpy),
+// the check field itself left out.
+uint64_t header_check(const SlabHeader &h) {
     const uint8_t *p = (const uint8_t *)&h;
+    const size_t skip = offsetof(SlabHeader, check);
     uint64_t a = 0xCBF29CE484222325ull;
-    for (size_t i = 0; i < sizeof h; i++) a = (a ^ p[i]) * 0x100000001B3ull;
+    for (size_t i = 0; i < sizeof h; i++)
+        if (i < skip || i >= skip + sizeof h.check) a = (a ^ p[i]) * 0x100000001B3ull;
     return a;
 }
 
@@ -112,8 +116,11 @@ uint64_t header_check(SlabHeader h) {
 // header's DevScene.
 struct SlabBuilder {
     std::vector<uint8_t> bytes;
-    SlabHeader hdr{};
-    SlabBuilder() { bytes.resize((sizeof(SlabHeader) + 255) & ~(size_t)255); }
+    SlabHeader hdr;
+    SlabBuilder() {
+        std::memset((void *)&hdr, 0, sizeof hdr);          // padding bytes too: the header is hashed as bytes
+        bytes.resize((sizeof(SlabHeader) + 255) & ~(size_t)255);
+    }
     template <typename T>
     void add(const T *src, size_t n, const T *DevScene::*field) {
         const size_t off = bytes.size(), nb = n * sizeof(T);
@@ -238,7 +245,12 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
     if (const char *e = getenv("PT_TUNE_REFINE")) { rp.enable = atoi(e) != 0; rp.rebuild = atoi(e) == 2; }
     if (const char *e = getenv("PT_TUNE_CI")) rp.ci = (float)atof(e);
     if (const char *e = getenv("PT_TUNE_LEAF")) rp.leaf_keep = atoi(e);
-    H.refine = refine_tree(d, rp, nf, frefs);
+    {
+        const RefineStats r = refine_tree(d, rp, nf, frefs);    // member by member: a struct copy need not keep H's zeroed padding
+        H.refine.nodes = r.nodes; H.refine.refs = r.refs; H.refine.leaves = r.leaves; H.refine.leaf_refs = r.leaf_refs;
+        H.refine.interior_refs = r.interior_refs; H.refine.new_nodes = r.new_nodes; H.refine.max_leaf = r.max_leaf;
+        H.refine.max_depth = r.max_depth;
+    }
     if (nf.size() >= (1u << 28) || (uint64_t)frefs.size() * 48u >= (1ull << 32))
         return fail(PT_ERR_LIMIT, "kd-tree too large for 32-bit byte offsets (2^28 nodes, 2^32 / 48 references)");
     // ---- per-reference triangle data in node order: v0, v1 - v0, v2 - v0 ----
@@ -349,7 +361,6 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
     S.ovf64_entries = (uint32_t)depth + 2u;
     std::memcpy(H.magic, "PTSLAB01", 8);
     H.total_bytes = B.bytes.size();
-    H.check = 0;
     H.check = header_check(H);
     std::memcpy(B.bytes.data(), &H, sizeof H);
     return PT_OK;

@@ -194,6 +194,16 @@ int pth_write_bmp(const char *path, const uint8_t *bgr, int rows, int cols) {
     return std::fclose(f) == 0 ? PT_OK : PT_ERR_INVALID;
 }
 
+int pth_write_jpeg(const char *path, const uint8_t *bgr, int rows, int cols, int quality) {
+    if (!path || !bgr || rows <= 0 || cols <= 0 || rows > 65535 || cols > 65535) { set_error("pth_write_jpeg: bad argument"); return PT_ERR_INVALID; }
+    try {
+        if (!pth::write_jpeg_file(path, bgr, rows, cols, quality)) { set_error(std::string("cannot write ") + path); return PT_ERR_INVALID; }
+    } catch (const std::bad_alloc &) {
+        return PT_ERR_OOM;
+    }
+    return PT_OK;
+}
+
 int pth_scene_make_atrium(uint32_t triangles, uint32_t seed, PthScene **out) {
     if (!out) { set_error("pth_scene_make_atrium: null argument"); return PT_ERR_INVALID; }
     PthScene *s = new (std::nothrow) PthScene();

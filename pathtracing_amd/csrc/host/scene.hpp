@@ -63,6 +63,7 @@ bool load_ppm(const std::string &path, Texture &out);
 bool decode_jpeg_file(const std::string &path, Texture &out);   // jpeg_decode.cpp
 bool decode_png_file(const std::string &path, Texture &out);    // png_decode.cpp
 bool decode_image_file(const std::string &path, Texture &out);  // by content: JPEG or PNG, whatever the file is called
+bool write_jpeg_file(const std::string &path, const uint8_t *bgr, int rows, int cols, int quality);   // jpeg_encode.cpp
 
 // kd_build.cpp
 void flatten_geometry(const Scene &scene, Flat &flat);

@@ -72,6 +72,7 @@ def lib():
         L.pth_decode_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
         L.pth_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         L.pth_write_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+        L.pth_write_jpeg.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.pth_scene_make_atrium.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         _lib = L
     return _lib
@@ -191,7 +192,12 @@ def decode_image(path):
 decode_jpeg = decode_image
 
 
-def write_image(path, bgr):
+def write_image(path, bgr, quality=95):
+    """By the file name's ending: .bmp, .jpg / .jpeg (baseline JPEG, quality as cv::imwrite's default), else PPM."""
     bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
-    fn = lib().pth_write_bmp if str(path).lower().endswith(".bmp") else lib().pth_write_ppm
+    low = str(path).lower()
+    if low.endswith(".jpg") or low.endswith(".jpeg"):
+        _check(lib().pth_write_jpeg(os.fsencode(path), bgr.ctypes.data, bgr.shape[0], bgr.shape[1], quality), "pth_write_jpeg")
+        return
+    fn = lib().pth_write_bmp if low.endswith(".bmp") else lib().pth_write_ppm
     _check(fn(os.fsencode(path), bgr.ctypes.data, bgr.shape[0], bgr.shape[1]), "pth_write_image")

@@ -84,6 +84,22 @@ def test_dataset_triplets(tmp_path, cbox):
             assert np.array_equal(read_ppm(files[k]), want), (v, k)
 
 
+def test_dataset_as_jpeg_files(tmp_path, cbox):
+    """--format jpg: the triplets under the reference's own file names (<scene><view>.jpg, what cv::imwrite wrote for its
+    data sets); each file decodes to the frame the C ABI renders, within JPEG error."""
+    from PIL import Image
+    hs, ds = cbox
+    run(["cbox", "-rm", "-gi", "--views", "1", "--size", "64", "--dataset", str(tmp_path / "data"), "--noisy-spp", "2",
+         "--converged-spp", "8", "--format", "jpg"], tmp_path)
+    cam = host.views_from_path(os.path.join(ROOT, "scenes", "paths", "cboxpath.txt"), hs.camera()["zoom"])[0]
+    for k, kw in (("4ssp", dict(gi=True, spp=2)), ("4096ssp", dict(gi=True, spp=8)), ("dif", dict(gi=False))):
+        f = tmp_path / "data" / "CBOX" / f"CBOX{k}" / "cbox0.jpg"
+        got = np.asarray(Image.open(f).convert("RGB"))[:, :, ::-1].astype(float)
+        want = ds.render(list(cam.eye), cam.angle, cam.zoom, size=64, aov=False, model=device.MODEL_OMP, view=0,
+                         gi_precision=device.GI_F32_FAST, **kw)["bgr"].astype(float)
+        assert got.shape == want.shape and np.sqrt(np.mean((got - want) ** 2)) < (12.0 if kw["gi"] else 4.0), k
+
+
 def test_rm_job_frames_do_not_depend_on_the_number_of_ranks(tmp_path, cbox):
     """`python -m pathtracing_amd.rm` (the -rm job, views dealt round-robin to ranks): one process and two processes
     (gloo rehearsal, both ranks on this GPU) write byte-identical frames, equal to what the C ABI renders."""

@@ -271,3 +271,31 @@ def test_damaged_packed_scene_is_refused(tmp_path):
             ("corrupt", lambda b: struct.pack_into("<I", b, at + 12, 0x7FFFFFFF))):                      # triangle count
         with pytest.raises(host.HostError, match=what):
             load(edit)
+
+
+def test_jpeg_writer_round_trip(tmp_path):
+    """Frames can be written the way the reference's data sets are (cv::imwrite of a .jpg): the file this build writes is
+    read back by Pillow and by this build's own decoder to within a few grey levels of the frame (quality 95, 4:2:0),
+    for sizes that are not multiples of the 16-pixel MCU, and lower quality gives a smaller file."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for rows, cols in ((1, 1), (37, 53), (64, 64)):
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        img = np.stack([127 + 120 * np.sin(xx / 9.0), 127 + 120 * np.cos(yy / 7.0), (xx * 3 + yy * 2) % 256], axis=2)
+        img = np.clip(img + rng.normal(0, 2, img.shape), 0, 255).astype(np.uint8)             # BGR
+        p = str(tmp_path / f"f{rows}x{cols}.jpg")
+        host.write_image(p, img)
+        pil = np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1]
+        own = host.decode_image(p)
+        assert pil.shape == own.shape == img.shape
+        if rows > 1:
+            # luma is kept closely; the blue ramp wraps every 85 pixels, which 4:2:0 smears, hence the looser colour bound
+            err = pil.astype(float) - img
+            luma = err @ np.array([0.114, 0.587, 0.299])
+            assert np.sqrt(np.mean(luma ** 2)) < 3.0 and np.sqrt(np.mean(err ** 2)) < 12.0
+        assert np.abs(pil.astype(int) - own.astype(int)).max() <= 2          # the two decoders agree on the file
+    big = str(tmp_path / "q95.jpg"); small = str(tmp_path / "q40.jpg")
+    host.write_image(big, img, quality=95); host.write_image(small, img, quality=40)
+    assert os.path.getsize(small) < os.path.getsize(big)
+    with pytest.raises(host.HostError):
+        host.write_image(str(tmp_path / "no_such_dir" / "x.jpg"), img)
