@@ -431,6 +431,7 @@ int scene_from_slab(const void *src, size_t bytes, bool src_is_device, PtScene *
     void *slab = nullptr;
     if (hipMalloc(&slab, bytes) != hipSuccess) return fail(PT_ERR_OOM, "out of device memory (scene slab)");
     hipError_t e = hipMemcpy(slab, src, bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();      // the caller may free or reuse `src` as soon as this returns
     if (e != hipSuccess) { (void)hipFree(slab); return fail(PT_ERR_HIP, std::string("scene slab copy: ") + hipGetErrorString(e)); }
     return finish_scene((uint8_t *)slab, H, g_device, out);
 }
@@ -1043,7 +1044,11 @@ int pt_scene_slab_size(const PtScene *sc, size_t *bytes) {
 int pt_scene_slab_export(const PtScene *sc, void *dst, size_t bytes, int dst_is_device) {
     if (!sc || !dst) return fail(PT_ERR_INVALID, "pt_scene_slab_export: null argument");
     if (bytes < sc->slab_bytes) return fail(PT_ERR_INVALID, "pt_scene_slab_export: destination too small");
+    HIPCHK(hipSetDevice(sc->device));
     HIPCHK(hipMemcpy(dst, sc->slab, sc->slab_bytes, dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    // a device-to-device copy may still be running when hipMemcpy returns; the caller hands `dst` to another stream or
+    // library (a collective) next, so the copy has to be complete
+    HIPCHK(hipDeviceSynchronize());
     return PT_OK;
 }
 
