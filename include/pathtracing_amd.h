@@ -178,7 +178,7 @@ int pt_render_view_device(PtScene *scene, const PtCamera *cam, const PtOptions *
 /* The view loop of renderMultiple() (mainOMP.cpp:225-247) for the views this
    process owns: n cameras -> n frames of size*size*3 bytes each, view index
    of camera i = view0 + i * view_stride (used as the RNG key word).
-   After pt_init(-1) on a machine with several GPUs the views are dealt round-robin to one worker thread per GPU
+   After pt_init(-1) on a machine with several GPUs one worker thread per GPU takes view after view from the list
    (the reference deals rows to MPI workers, mainOMP.cpp:169-174; here the unit is the view) and every GPU copies its
    frames into `frames` itself.  The frames are the same bytes for any number of GPUs. */
 int pt_render_views(PtScene *scene, const PtCamera *cams, size_t n, uint32_t view0, uint32_t view_stride,

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstddef>
@@ -981,9 +982,11 @@ int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0,
     std::lock_guard<std::mutex> lock(sc->busy);
     auto t0 = std::chrono::steady_clock::now();
     const size_t frame_bytes = (size_t)size * size * 3;
-    // One worker per device: worker w renders the views i with i % workers == w on its copy of the scene and copies
-    // each frame straight into the caller's array (every GPU over its own PCIe link; nothing is routed through the
-    // first GPU).  The frames do not depend on the number of workers: the RNG is keyed by the view index.
+    // One worker per device, each on its own copy of the scene: a worker takes the next view that nobody has taken yet
+    // (views differ in cost by tens of percent, so dealing them out in advance -- the reference deals rows round-robin,
+    // mainOMP.cpp:169-174 -- would leave GPUs waiting at the end) and copies each frame straight into the caller's array
+    // (every GPU over its own PCIe link; nothing is routed through the first GPU).  The frames do not depend on the
+    // number of workers or on who renders what: the RNG is keyed by the view index.
     const std::vector<int> devs = worker_devices();
     rc = ensure_replicas(sc, devs);
     if (rc) return rc;
@@ -991,6 +994,8 @@ int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0,
     std::vector<int> wrc(W, PT_OK);
     std::vector<std::string> werr(W);
     std::vector<PtStats> wst(W);
+    std::atomic<size_t> next_view{0};
+    std::atomic<bool> stop{false};                         // a worker failed: the others take no further view
     auto work = [&](size_t w) {
         PtScene *my = w == 0 ? sc : sc->replicas[w - 1];
         PtStats *st = stats ? &wst[w] : nullptr;
@@ -998,7 +1003,7 @@ int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0,
         int r = PT_OK;
         if (hipSetDevice(my->device) != hipSuccess) r = fail(PT_ERR_HIP, "hipSetDevice failed in a view worker");
         PtOptions o = *opt;
-        for (size_t i = w; i < n && !r; i += W) {
+        for (size_t i; !r && !stop.load() && (i = next_view.fetch_add(1)) < n;) {
             o.view = view0 + (uint32_t)i * view_stride;
             float gi_ms; uint64_t gi_l;
             r = render_on_device(my, &cams[i], &o, st, &gi_ms, &gi_l);
@@ -1008,13 +1013,13 @@ int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0,
         }
         if (!r && hipStreamSynchronize(my->stream) != hipSuccess) r = fail(PT_ERR_HIP, "stream synchronisation failed");
         wrc[w] = r;
-        if (r) werr[w] = g_error;                          // the message lives in the worker's thread
+        if (r) { werr[w] = g_error; stop.store(true); }    // the message lives in the worker's thread
     };
     if (W == 1) {
         work(0);
     } else {
         std::vector<std::thread> threads;
-        for (size_t w = 0; w < W; w++) threads.emplace_back([&, w] { try { work(w); } catch (...) { wrc[w] = PT_ERR_OOM; werr[w] = "exception in a view worker"; } });
+        for (size_t w = 0; w < W; w++) threads.emplace_back([&, w] { try { work(w); } catch (...) { wrc[w] = PT_ERR_OOM; werr[w] = "exception in a view worker"; stop.store(true); } });
         for (std::thread &t : threads) t.join();
         (void)hipSetDevice(sc->device);
     }
