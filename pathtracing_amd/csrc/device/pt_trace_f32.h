@@ -153,7 +153,7 @@ __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2
             ovf[(size_t)L.novf * 64] = stk[((L.top + 1u) & slot_mask) * 64];      // the oldest entry leaves the ring
             L.novf++;
         } else {
-            atomicOr(S.err, (unsigned long long)PT_LIMIT_F32_STACK);   // the entry is lost: the call fails with PT_ERR_LIMIT
+            atomicOr((unsigned int *)S.err, (unsigned int)PT_LIMIT_F32_STACK);   // the entry is lost: the call fails with PT_ERR_LIMIT
         }
     }
     stk[L.top * 64] = make_uint2(fr, __float_as_uint(L.ext));      // slot `top` is always free
@@ -166,7 +166,7 @@ __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2
     L.top = push ? ((L.top + 1u) & slot_mask) : (pop_ring ? ptop : L.top);
     L.cs += 256u + (uint32_t)(push & !full) - (uint32_t)pop_ring;
     const bool runaway = L.cs > ((uint32_t)FS_MAX_STEPS << 8);
-    if (runaway) atomicOr(S.err, (unsigned long long)PT_LIMIT_F32_STEPS);          // never seen; ends the ray so that the wave ends
+    if (runaway) atomicOr((unsigned int *)S.err, (unsigned int)PT_LIMIT_F32_STEPS);          // never seen; ends the ray so that the wave ends
     done = finished | exhausted | runaway;
     load_node(L, S, curr);
     if (COUNT && !done) { work[0]++; work[1] += (L.tend - L.toff) / 48u; }
