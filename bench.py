@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1024, help="GI samples per pixel (the reference's converged sponza/room renders use 1024)")
     ap.add_argument("--model", default="omp", choices=["main", "omp"])
     ap.add_argument("--rb", action="store_true")
+    ap.add_argument("--views-per-step", type=int, default=1,
+                    help="views each GPU renders per step, handed to the library in one call (it keeps several small views in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path with every rank on GPU 0 and the exchanges staged through host memory")
@@ -284,13 +286,26 @@ def main():
     frame = torch.empty(size * size * 3, dtype=torch.uint8, device=dev)
     # Finished frames go to rank 0 in one gather per 8 steps (and at the end of the warm-up and of the timed steps):
     # a gather makes the ranks wait for each other, and views differ in cost.
-    gather = multiview.FrameGather(frame.numel(), xdev, dist, batch=8) if world > 1 else None
+    B = max(1, a.views_per_step)
+    gather = multiview.FrameGather(frame.numel(), xdev, dist, batch=8 * B) if world > 1 else None
 
     # Weak scaling: step i renders camera i of the path on every rank, each rank with its own RNG key (the view index
     # i * world + rank of the multi-view job), so that the work per GPU is the same for every N and the N = 1, 2, 4, 8
     # lines differ by what the extra GPUs cost, not by which cameras happened to fall to them (views differ in cost
     # by tens of percent).
     def step(i, stats):
+        if B > 1:
+            # B views per rank in one call: cameras i*B .. i*B + B - 1 of the path, view indices (i*B + j) * world + rank
+            frames, sd = ds.render_views([views[(i * B + j) % nviews] for j in range(B)], view0=i * B * world + rank,
+                                         view_stride=world, **opt)
+            for k in ("primary", "shadow", "mirror", "gi", "omp_retrace", "ms_gi_trace", "gi_trace_launches"):
+                setattr(stats, k, getattr(stats, k) + sd[k])
+            if world > 1:
+                for j in range(B):
+                    gather.slot(i * B + j).copy_(torch.from_numpy(frames[j].reshape(-1)))
+                if gather.full():
+                    gather.flush(1 << 30)
+            return
         ds.render_to_device(views[i % nviews], frame.data_ptr(), stats=stats, view=i * world + rank, **opt)
         if world > 1:
             gather.slot(i).copy_(frame if a.backend == "nccl" else frame.cpu())
@@ -332,7 +347,7 @@ def main():
         # ---- algorithmic bytes per ray of the dominant kernel: a counting run (untimed) ----
         # over exactly the views the timed steps of this rank rendered
         c_gi = c_node = c_tri = 0
-        for i in range(a.warmup, a.warmup + a.steps):
+        for i in range(a.warmup * B, (a.warmup + a.steps) * B):
             cst = device.PtStats()
             ds.render_to_device(views[i % nviews], frame.data_ptr(), stats=cst, view=i * world + rank,
                                 flags=device.FLAG_COUNT_WORK, **opt)
@@ -406,10 +421,12 @@ def main():
             "dtype": "f32 (GI sample rays) + f64 (primary, mirror, their shadow rays)",
             "data": "synthetic" if a.workload == "atrium" else ("scene directory supplied by the user" if a.workload == "sponza" else "reference scene file, packed"),
             "config": {"workload": WORKLOADS[a.workload][2], "spp": a.spp, "model": a.model, "rb": bool(a.rb),
-                       "image": "512x512", "views_per_step": world, "parallelism": f"one view per GPU per step on {world} GPU(s): camera = step, RNG key = step * GPUs + rank; frames gathered on rank 0",
+                       "image": "512x512", "views_per_step": world * B,
+                       "parallelism": (f"one view per GPU per step on {world} GPU(s): camera = step, RNG key = step * GPUs + rank; frames gathered on rank 0" if B == 1 else
+                                       f"{B} views per GPU per step on {world} GPU(s), one library call per step; frames gathered on rank 0"),
                        "triangles": st["triangles"], "kd_refs": st["optimized"], "kd_nodes": st["nodes"],
                        "device_tree": ds.info()},
-            "views_per_s": round(a.steps * world / dt_max, 3),
+            "views_per_s": round(a.steps * world * B / dt_max, 3),
             "gi_mrays_per_s": round(gi_total / dt_max / 1e6, 1),
             "scene_setup_s": round(scene_seconds, 2),
             "roofline": roofline,

@@ -178,9 +178,11 @@ int pt_render_view_device(PtScene *scene, const PtCamera *cam, const PtOptions *
 /* The view loop of renderMultiple() (mainOMP.cpp:225-247) for the views this
    process owns: n cameras -> n frames of size*size*3 bytes each, view index
    of camera i = view0 + i * view_stride (used as the RNG key word).
-   After pt_init(-1) on a machine with several GPUs one worker thread per GPU takes view after view from the list
-   (the reference deals rows to MPI workers, mainOMP.cpp:169-174; here the unit is the view) and every GPU copies its
-   frames into `frames` itself.  The frames are the same bytes for any number of GPUs. */
+   Views are taken from the list one after another by worker threads (the reference deals rows to MPI workers,
+   mainOMP.cpp:169-174; here the unit is the view): after pt_init(-1) every GPU has its own copy of the scene and copies
+   its frames into `frames` itself, and on each GPU up to four workers share that copy when a view is small (under
+   8 Mi GI sample rays per worker's view, e.g. 512 x 512 at 16 spp), so that several views are in flight and the GPU stays
+   full; each worker keeps a workspace of its own.  The frames are the same bytes for any number of GPUs and workers. */
 int pt_render_views(PtScene *scene, const PtCamera *cams, size_t n, uint32_t view0, uint32_t view_stride,
                     const PtOptions *opt, uint8_t *frames, PtStats *stats);
 

@@ -150,7 +150,7 @@ int main(int argc, char **argv) {
         }
         if (dataset.empty() && all_gpus) {
             // the view loop inside the library: batches of views, sharded over the GPUs, frames written between batches
-            const size_t batch = 8 * (size_t)pt_device_count();
+            const size_t batch = 32 * (size_t)pt_device_count();
             std::vector<uint8_t> frames[2] = {std::vector<uint8_t>(batch * frame.size()), std::vector<uint8_t>(batch * frame.size())};
             std::thread writer;                                 // writes the files of one batch while the next one renders
             int write_failed = 0;

@@ -95,6 +95,8 @@ struct PtScene {
     uint32_t n_tri = 0, n_mesh = 0;
     std::vector<int32_t> tri_mesh, tri_local;   // host copies for (mesh, tri) reporting
     std::vector<PtScene *> replicas;            // copies of this scene on the other initialised devices (pt_render_views)
+    std::vector<PtScene *> sharers;             // further view workers on this device: own scratch, streams and workspace around this scene's slab
+    bool slab_borrowed = false;                 // the slab belongs to the scene this one is a sharer of
     std::mutex busy;                            // calls on one scene are serialised: it has one workspace, one stream pair
 };
 
@@ -376,13 +378,15 @@ int check_slab_header(const SlabHeader &H, size_t bytes) {
     return PT_OK;
 }
 
-// A scene on the current device around a slab that is already there (`slab`, owned by the scene from here on): binds the
-// pointers, allocates the scene's own scratch, streams and events, fetches the two host-side index tables.
-int finish_scene(uint8_t *slab, const SlabHeader &H, int device, PtScene **out) {
+// A scene on the current device around a slab that is already there (`slab`, owned by the scene from here on unless
+// `borrowed`: then it stays with the scene that lends it): binds the pointers, allocates the scene's own scratch,
+// streams and events, fetches the two host-side index tables.
+int finish_scene(uint8_t *slab, const SlabHeader &H, int device, PtScene **out, bool borrowed = false) {
     struct Free { void operator()(PtScene *p) const { pt_scene_free(p); } };
     std::unique_ptr<PtScene, Free> holder(new (std::nothrow) PtScene());
     PtScene *sc = holder.get();
-    if (!sc) { (void)hipFree(slab); return fail(PT_ERR_OOM, "out of host memory"); }
+    if (!sc) { if (!borrowed) (void)hipFree(slab); return fail(PT_ERR_OOM, "out of host memory"); }
+    sc->slab_borrowed = borrowed;
     sc->slab = slab; sc->slab_bytes = (size_t)H.total_bytes; sc->device = device;
     sc->dev_bytes = H.total_bytes;
     sc->max_depth = H.max_depth; sc->refine = H.refine; sc->n_tri = H.n_tri; sc->n_mesh = H.n_mesh;
@@ -712,6 +716,38 @@ int ensure_replicas(PtScene *sc, const std::vector<int> &devs) {
     return PT_OK;
 }
 
+// Makes sure `base` has at least k - 1 sharers: view workers on its device that use its slab (the scene is immutable)
+// with scratch, streams and workspace of their own.
+int ensure_sharers(PtScene *base, size_t k) {
+    if (base->sharers.size() + 1 >= k) return PT_OK;
+    HIPCHK(hipSetDevice(base->device));
+    SlabHeader H;
+    HIPCHK(hipMemcpy(&H, base->slab, sizeof H, hipMemcpyDeviceToHost));
+    while (base->sharers.size() + 1 < k) {
+        PtScene *r = nullptr;
+        int rc = finish_scene(base->slab, H, base->device, &r, true);
+        if (rc) return rc;
+        base->sharers.push_back(r);
+    }
+    return PT_OK;
+}
+
+// View workers per device copy of the scene.  One view of a few million rays does not fill the GPU from end to end:
+// its kernels have ramps and tails, the fp64 primary pass and the fp32 traversal are bound by different units, and
+// the host submits between them; two to four views in flight on streams of their own fill those gaps (car, 16 spp,
+// -rb: 585 -> 691 views/s with four).  A view whose GI pass alone is tens of millions of rays gains nothing and
+// its workspace is gigabytes, so it keeps one worker.  PT_TUNE_WORKERS overrides the choice.
+size_t workers_per_device(size_t views_per_device, int size, int gi, int spp) {
+    if (const char *e = getenv("PT_TUNE_WORKERS")) {
+        const int k = atoi(e);
+        if (k >= 1 && k <= 8) return (size_t)k;
+    }
+    const size_t load = (size_t)size * size * (size_t)(gi ? (spp > 1 ? spp : 1) : 1);
+    size_t k = ((size_t)32 << 20) / (load ? load : 1);
+    k = k < 1 ? 1 : (k > 4 ? 4 : k);
+    return k < views_per_device ? k : (views_per_device ? views_per_device : 1);
+}
+
 template <typename T>
 int fetch(PtScene *sc, T *host, const T *dev, size_t n) {
     if (!host) return PT_OK;
@@ -772,12 +808,13 @@ int pt_scene_info(const PtScene *sc, PtSceneInfo *out) {
 int pt_scene_free(PtScene *sc) {
     if (!sc) return PT_OK;
     for (PtScene *r : sc->replicas) pt_scene_free(r);
+    for (PtScene *r : sc->sharers) pt_scene_free(r);
     int prev = -1;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(sc->device);
     ws_release(sc->ws);
     for (void *p : sc->owned) (void)hipFree(p);
-    if (sc->slab) (void)hipFree(sc->slab);
+    if (sc->slab && !sc->slab_borrowed) (void)hipFree(sc->slab);
     if (sc->ev0) (void)hipEventDestroy(sc->ev0);
     if (sc->ev1) (void)hipEventDestroy(sc->ev1);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
@@ -990,14 +1027,23 @@ int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0,
     const std::vector<int> devs = worker_devices();
     rc = ensure_replicas(sc, devs);
     if (rc) return rc;
-    const size_t W = devs.size();
+    const size_t per_dev = workers_per_device((n + devs.size() - 1) / devs.size(), size, opt->gi, N);
+    std::vector<PtScene *> workers;
+    std::vector<int> wdev;
+    for (size_t d = 0; d < devs.size(); d++) {
+        PtScene *base = d == 0 ? sc : sc->replicas[d - 1];
+        if ((rc = ensure_sharers(base, per_dev))) return rc;
+        for (size_t k = 0; k < per_dev; k++) { workers.push_back(k == 0 ? base : base->sharers[k - 1]); wdev.push_back(devs[d]); }
+    }
+    (void)hipSetDevice(sc->device);
+    const size_t W = workers.size();
     std::vector<int> wrc(W, PT_OK);
     std::vector<std::string> werr(W);
     std::vector<PtStats> wst(W);
     std::atomic<size_t> next_view{0};
     std::atomic<bool> stop{false};                         // a worker failed: the others take no further view
     auto work = [&](size_t w) {
-        PtScene *my = w == 0 ? sc : sc->replicas[w - 1];
+        PtScene *my = workers[w];
         PtStats *st = stats ? &wst[w] : nullptr;
         if (st) std::memset(st, 0, sizeof *st);
         int r = PT_OK;
@@ -1024,7 +1070,7 @@ int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0,
         (void)hipSetDevice(sc->device);
     }
     for (size_t w = 0; w < W; w++)
-        if (wrc[w]) return fail(wrc[w], "view worker " + std::to_string(w) + " (device " + std::to_string(devs[w]) + "): " + werr[w]);
+        if (wrc[w]) return fail(wrc[w], "view worker " + std::to_string(w) + " (device " + std::to_string(wdev[w]) + "): " + werr[w]);
     if (stats) {
         for (size_t w = 0; w < W; w++) {
             stats->primary += wst[w].primary; stats->shadow += wst[w].shadow; stats->mirror += wst[w].mirror; stats->gi += wst[w].gi;

@@ -138,12 +138,16 @@ class FrameGather:
         self.flush(n_views, out)
 
 
-def run_views(render, n_views, frame_numel, device, dist, on_frame=None, batch=8):
+def run_views(render, n_views, frame_numel, device, dist, on_frame=None, batch=8, render_many=None):
     """The -rm job (renderMultiple, mainOMP.cpp:225-247) over all ranks: view v is rendered by rank v % world.
 
     render(v) -> uint8 tensor of frame_numel bytes on `device` (called only for views this rank owns; the tensor may
     be reused by the next call); on_frame(v, numpy frame) is called on rank 0 for every view, in view order.  The
-    ranks meet once per `batch` rounds.  Works without a process group (world 1).  Returns the number of rounds."""
+    ranks meet once per `batch` rounds.  Works without a process group (world 1).  Returns the number of rounds.
+
+    render_many(first_view, stride, count) -> uint8 numpy array (count, frame_numel), the frames of views first_view,
+    first_view + stride, ...: when given, a rank renders the views of a whole batch of rounds in one call (the library
+    then keeps several of them in flight on the GPU) instead of one `render` call per view."""
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     gather = FrameGather(frame_numel, device, dist, batch) if world > 1 else None
@@ -155,6 +159,27 @@ def run_views(render, n_views, frame_numel, device, dist, on_frame=None, batch=8
         if rank == 0 and on_frame is not None:
             for vv in sorted(got):
                 on_frame(vv, got[vv])
+
+    if render_many is not None:
+        import torch
+        for k0 in range(0, n_rounds, max(1, int(batch))):
+            nb = min(max(1, int(batch)), n_rounds - k0)
+            first = k0 * world + rank
+            mine = len(range(first, min(n_views, (k0 + nb) * world), world)) if first < n_views else 0
+            frames = render_many(first, world, mine) if mine else None
+            if world == 1:
+                if on_frame is not None:
+                    for j in range(mine):
+                        on_frame(first + j, frames[j])
+                continue
+            for j in range(nb):
+                slot = gather.slot(k0 + j)
+                if j < mine:
+                    slot.copy_(torch.from_numpy(frames[j]))
+                else:
+                    slot.zero_()
+            deliver()
+        return n_rounds
 
     for k in range(n_rounds):
         v = k * world + rank

@@ -80,6 +80,13 @@ def main(argv=None):
                             part=part, n_parts=n_parts, **opt)
         return frame if a.backend == "nccl" else frame.cpu()
 
+    def render_many(first, stride, count):
+        """Views first, first + stride, ... in one library call, which keeps several of them in flight on the GPU."""
+        sel = cams[first: first + stride * count: stride]
+        frames, _ = ds.render_views([device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])) for c in sel],
+                                    view0=first, view_stride=stride, **opt)
+        return frames.reshape(count, -1)
+
     t_last = [time.perf_counter()]
     # Files are written by a few more threads, so that the GPU renders the next views meanwhile (the render call and the
     # file write both release the interpreter lock).  Eight GPUs at 300 views/s each hand rank 0 about 2 GB/s of frames:
@@ -113,7 +120,8 @@ def main(argv=None):
     if a.split_rows:
         multiview.run_split_views(render, len(cams), n, xdev, dist if world > 1 else None, on_frame if rank == 0 else None)
     else:
-        multiview.run_views(render, len(cams), frame.numel(), xdev, dist if world > 1 else None, on_frame if rank == 0 else None)
+        multiview.run_views(render, len(cams), frame.numel(), xdev, dist if world > 1 else None, on_frame if rank == 0 else None,
+                            batch=32, render_many=render_many)
     if wthreads:
         for _ in wthreads:
             pending.put(None)

@@ -41,6 +41,17 @@ def main():
 
     n_rounds = multiview.run_views(render, n_views, 48, dev, dist, (lambda v, px: got.__setitem__(v, px)) if rank == 0 else None)
     assert n_rounds == multiview.rounds(n_views, world)
+    # the same job with a whole batch of rounds rendered per call; a batch size that divides neither the rounds nor the views
+    got_many, calls = {}, []
+
+    def render_many(first, stride, count):
+        assert first % world == rank and stride == world and count >= 1
+        calls.append(count)
+        return np.stack([np.full(48, ((first + j * stride) * 7) % 251, np.uint8) for j in range(count)])
+
+    multiview.run_views(None, n_views, 48, dev, dist, (lambda v, px: got_many.__setitem__(v, px.copy())) if rank == 0 else None,
+                        batch=5, render_many=render_many)
+    assert sum(calls) == len(mine) and max(calls) <= 5
     # one view split over the ranks by row bands; sizes that are not multiples of 8 rows or of the world size
     split_ok = True
     for size in (20, 64, 9):
@@ -62,7 +73,8 @@ def main():
     dist.barrier()
     if rank == 0:
         ok = (split_ok and len(set(digests)) == 1 and sorted(sum(owners, [])) == list(range(n_views)) and sorted(got) == list(range(n_views))
-              and all((got[v] == (v * 7) % 251).all() for v in got))
+              and all((got[v] == (v * 7) % 251).all() for v in got)
+              and sorted(got_many) == list(range(n_views)) and all((got_many[v] == (v * 7) % 251).all() for v in got_many))
         print(json.dumps({"ok": bool(ok), "world": world, "views": n_views, "blob_bytes": int(blob.size),
                           "max_share": max(len(o) for o in owners), "min_share": min(len(o) for o in owners)}))
     dist.destroy_process_group()

@@ -159,7 +159,8 @@ def test_bench_with_two_ranks_started_by_itself(cbox):
 
 
 def test_view_loop_over_several_workers_gives_the_same_frames(tmp_path, cbox, monkeypatch):
-    """pt_render_views deals the views round-robin to one worker thread per device, each with its own copy of the scene.
+    """pt_render_views hands the views to worker threads: one copy of the scene per device, and on every device up to
+    four workers that share that copy (several small views in flight fill the GPU better than one).
     On a one-GPU machine the workers all use that GPU (PT_TUNE_REPLICAS): three workers -- scene copied device to
     device, and once more through an RCCL broadcast in a communicator of one rank, so that the RCCL calls run too --
     write exactly the frames of one worker, with the same ray counts; `ptmain -rm --gpus all` on top of it writes the
@@ -168,7 +169,17 @@ def test_view_loop_over_several_workers_gives_the_same_frames(tmp_path, cbox, mo
     cams = host.views_from_path(os.path.join(ROOT, "scenes", "paths", "cboxpath.txt"), hs.camera()["zoom"])[:7]
     kw = dict(gi=True, rb=True, spp=4, size=64, model=device.MODEL_OMP, gi_precision=device.GI_F32_FAST)
     monkeypatch.delenv("PT_TUNE_REPLICAS", raising=False)
+    monkeypatch.setenv("PT_TUNE_WORKERS", "1")
     one, st1 = ds.render_views(cams, view0=0, view_stride=1, **kw)
+    for workers in ("4", None):                                 # four workers on the one copy; the library's own choice
+        if workers is None:
+            monkeypatch.delenv("PT_TUNE_WORKERS")
+        else:
+            monkeypatch.setenv("PT_TUNE_WORKERS", workers)
+        shared, sts = ds.render_views(cams, view0=0, view_stride=1, **kw)
+        assert np.array_equal(one, shared)
+        for k in ("primary", "gi", "mirror", "shadow", "omp_retrace"):
+            assert st1[k] == sts[k], k
     for self_rccl in ("0", "1"):
         monkeypatch.setenv("PT_TUNE_REPLICAS", "3")
         monkeypatch.setenv("PT_TUNE_RCCL_SELF", self_rccl)
