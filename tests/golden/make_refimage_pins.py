@@ -18,7 +18,11 @@ What was found for cbox (scenes/cbox, scenes/paths/cboxpath.txt; frame k = posit
   place and are left out.
 * ml/data/CAR/* was rendered from an arrangement of the car scene that differs from the shipped scenes/car
   (the room is smaller and the car fills more of the frame at every position; a grid + simplex search over the
-  eye position leaves an RMSE above 20 / 255), so no car frame can serve as a pin.
+  eye position leaves an RMSE above 20 / 255), so no car frame can serve as a pin.  Blind matching (every 8th
+  path view rendered without -gi in both shading models, each compared with all 320 CARdif frames) does find
+  pairs at 2.8-5 / 255, but they are the data set's darkest frames (mean brightness 14-20 of 255; frames 135, 165,
+  167 and 183 are the "best match" of two dozen different views each) with no relation between the indices, while
+  the frame of the same index is 12-70 / 255 away: agreement of mostly black pictures, not of renders.
 
 A size-S render samples the image plane at j / S, so pixel (i, j) of a 32 x 32 render is exactly pixel
 (16 i, 16 j) of the 512 x 512 frame: the fixture keeps every 16th pixel of every 16th row.
