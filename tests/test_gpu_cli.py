@@ -156,6 +156,14 @@ def test_bench_with_two_ranks_started_by_itself(cbox):
     # weak scaling: every rank renders the same cameras, so the job traced twice the rays
     rays = lambda j: j["value"] * 1e6 * j["ms_per_step"] * 1e-3 * j["steps"]
     assert abs(rays(two) / rays(one) - 2.0) < 0.02
+    # several views per rank and step, handed to the library in one call (which keeps them in flight together)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "cbox", "--spp", "16",
+                        "--steps", "2", "--warmup", "1", "--views-per-step", "3", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    many = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(many) == 1 and many[0]["config"]["views_per_step"] == 6 and many[0]["n_gpus"] == 2
+    assert abs(many[0]["views_per_s"] * many[0]["ms_per_step"] * 1e-3 - 6.0) < 0.01
 
 
 def test_view_loop_over_several_workers_gives_the_same_frames(tmp_path, cbox, monkeypatch):
