@@ -11,8 +11,10 @@
 //   k_shadow_gi     MAIN model: any-hit traversal towards every light (same machinery)
 //   k_gi_sum        ordered per-pixel sum of the pass's contributions (fp64)
 //
-// Every sample owns a contribution slot, so the image does not depend on the order in
-// which waves draw from the queues.
+// A contribution is stored at its ray's place in the queue (streamed, not scattered) and carries the
+// ray's (sample, pixel) code; the summing block of a tile sorts them by that code in LDS and adds each
+// pixel's samples in sample order, so the image does not depend on the order in which waves draw from
+// the queues or on how the generator sorted the rays.
 #include <float.h>
 #include <stdlib.h>
 
@@ -151,8 +153,8 @@ __global__ void __launch_bounds__(1024) k_tile_scan(FastBuffers Q, int tiles) {
 // One block = one 8x8 pixel tile x up to 64 samples of the pass (thread = pixel x sample lane,
 // four samples each): 4096 rays with nearby origins.  They are written to the queue sorted by
 // direction bin (counting sort in LDS), so that the 64 rays a wave of the closest-hit kernel
-// draws together start close to each other and point the same way.  Queue order is free: the
-// contribution slot travels with the ray.
+// draws together start close to each other and point the same way.  Queue order inside the block is
+// free: the ray's code, (sample of the pass) * 64 + (pixel of the tile), travels with it.
 #define PT_GEN_AXIS_BITS 3                          // direction cells per axis = 1 << bits
 #define PT_GEN_BINS (1 << (3 * PT_GEN_AXIS_BITS))
 __device__ __forceinline__ uint32_t dir_bin(float x, float y, float z) {
@@ -173,7 +175,7 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
     const int tile = ordered_tile(qtile, V.size);
     int i, j;
     const bool live = tile_pixel_f(tile * 64 + (tid & 63), V.size, i, j);
-    const size_t P = (size_t)V.size * V.size, p = live ? (size_t)i * V.size + j : 0;
+    const size_t p = live ? (size_t)i * V.size + j : 0;
     for (int k = tid; k < PT_GEN_BINS; k += 1024) hist[k] = 0;
     __syncthreads();
     bool pix_valid = false;
@@ -256,7 +258,7 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
             const uint32_t q = block_base + bin_base[key[r]] + rank[r];
             Q.rays_o[q] = ro;
             Q.rays_d[q] = rd[r];
-            Q.ray_slot[q] = (uint32_t)((size_t)sl * P + p);
+            Q.ray_slot[q] = (uint32_t)sl * 64u + (uint32_t)(tid & 63);
             if (__float_as_uint(rd[r].w) >> 31) Q.hits[q] = make_float4(st[r], su[r], sv[r], __int_as_float(otri));
         }
     }
@@ -380,9 +382,8 @@ __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBu
     if (in_range) {
         float4 h = Q.hits[r];
         int tri = __float_as_int(h.w);
-        uint32_t slot = Q.ray_slot[r];
         if (tri < 0) {
-            Q.contrib[slot] = make_float4(0.f, 0.f, 0.f, 0.f);     // castRay returns 0 on a miss at depth -1
+            Q.contrib[r] = make_float4(0.f, 0.f, 0.f, 0.f);        // castRay returns 0 on a miss at depth -1
         } else {
             float4 o = Q.rays_o[r], d = Q.rays_d[r];
             float ar, ag, ab;
@@ -412,12 +413,12 @@ __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBu
                     dr += c * sr; dg += c * sg; db += c * sb;
                 }
                 float k = fabsf(d.w) * (1.0f / 3.14159265358979f);
-                Q.contrib[slot] = make_float4(k * ar * dr, k * ag * dg, k * ab * db, 0.f);
+                Q.contrib[r] = make_float4(k * ar * dr, k * ag * dg, k * ab * db, 0.f);
             } else {
                 hit = true;
                 float k = fabsf(d.w) * 0.6f * (1.0f / 3.14159265358979f);            // main.cpp:77 with ref = 0
                 sp_pos = make_float4(hx, hy, hz, __int_as_float(tri));
-                sp_nrm = make_float4(sf.nx, sf.ny, sf.nz, __uint_as_float(slot));
+                sp_nrm = make_float4(sf.nx, sf.ny, sf.nz, __uint_as_float(r));
                 sp_base = make_float4(k * ar, k * ag, k * ab, 0.f);
             }
         }
@@ -503,22 +504,42 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
 }
 
 // ---- stage 5: indirect += r1 * L over the pass's samples, in sample order ------------
-__global__ void k_gi_sum(FrameBuffers F, FastBuffers Q, int size, int nb, int first_batch) {
-    size_t P = (size_t)size * size, p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p == 0) {                                   // the pass's ray counts join the totals of the view (read once, at its end)
+// One block per 8x8 pixel tile.  The tile's contributions lie in the queue where its rays lay: per group of up to 64
+// samples one run of (valid pixels x samples) entries in the generator's sort order.  The block streams a run in,
+// drops every entry into LDS at the place its code names -- the scatter that sorting the rays made necessary happens
+// in LDS, not in device memory, where 16-byte writes at random places cost the shading kernel 0.7 ms per 67 M rays --
+// and then every pixel adds its samples in sample order in fp64, as the reference's loop does (main.cpp:129-133).
+#define PT_SUM_THREADS 256
+__global__ void __launch_bounds__(PT_SUM_THREADS) k_gi_sum(FrameBuffers F, FastBuffers Q, int size, int nb, int first_batch) {
+    __shared__ float cr[64 * 64], cg[64 * 64], cb[64 * 64];
+    const int tid = threadIdx.x, qtile = blockIdx.x;
+    if (qtile == 0 && tid == 0) {                   // the pass's ray counts join the totals of the view (read once, at its end)
         Q.totals[0] += Q.counts[0];
         Q.totals[1] += Q.counts[2];
     }
-    if (p >= P) return;
+    const int tile = ordered_tile(qtile, size);
+    const uint32_t t0 = Q.tile_base[qtile], valid = Q.tile_base[qtile + 1] - t0;
+    int i, j;
+    const bool mine = tid < 64 && tile_pixel_f(tile * 64 + tid, size, i, j);
+    const size_t p = mine ? (size_t)i * size + j : 0;
     double ax = 0, ay = 0, az = 0;
-    if (!first_batch) { ax = F.gi_acc[3 * p]; ay = F.gi_acc[3 * p + 1]; az = F.gi_acc[3 * p + 2]; }
-    // a pixel without a primary hit shot no rays: its slots were never written (main.cpp:86 returns 0 for it)
-    const int live = F.ghit[3 * p] == -99999 ? 0 : nb;
-    for (int s = 0; s < live; s++) {
-        float4 c = Q.contrib[(size_t)s * P + p];
-        ax += (double)c.x; ay += (double)c.y; az += (double)c.z;
+    if (mine && !first_batch) { ax = F.gi_acc[3 * p]; ay = F.gi_acc[3 * p + 1]; az = F.gi_acc[3 * p + 2]; }
+    // a pixel without a primary hit shot no rays (main.cpp:86 returns 0 for it)
+    const bool shot = mine && !(F.ghit[3 * p] == -99999);
+    for (int g0 = 0; g0 < nb && valid; g0 += 64) {
+        const int gs = nb - g0 < 64 ? nb - g0 : 64;
+        const uint32_t base = t0 * (uint32_t)nb + valid * (uint32_t)g0, n = valid * (uint32_t)gs;
+        for (uint32_t k = tid; k < n; k += PT_SUM_THREADS) {
+            const float4 c = Q.contrib[base + k];
+            const uint32_t at = Q.ray_slot[base + k] - (uint32_t)g0 * 64u;
+            cr[at] = c.x; cg[at] = c.y; cb[at] = c.z;
+        }
+        __syncthreads();
+        if (shot)
+            for (int s = 0; s < gs; s++) { ax += (double)cr[s * 64 + tid]; ay += (double)cg[s * 64 + tid]; az += (double)cb[s * 64 + tid]; }
+        __syncthreads();
     }
-    F.gi_acc[3 * p] = ax; F.gi_acc[3 * p + 1] = ay; F.gi_acc[3 * p + 2] = az;
+    if (mine) { F.gi_acc[3 * p] = ax; F.gi_acc[3 * p + 1] = ay; F.gi_acc[3 * p + 2] = az; }
 }
 
 // ---- raw queries for tests: fp64 in/out around the fp32 traversal -------------------
@@ -666,7 +687,7 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         } else {
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_OMP>, dim3(sblocks), dim3(PT_APPEND_BLOCK), (size_t)tune.shade_lds, s, S, Q);
         }
-        hipLaunchKernelGGL(k_gi_sum, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, F, Q, V.size, nb, s0 == 0);
+        hipLaunchKernelGGL(k_gi_sum, dim3((unsigned)(tthreads / 64)), dim3(PT_SUM_THREADS), 0, s, F, Q, V.size, nb, s0 == 0);
         FQ(hipEventRecord(events[4 * pass + 3], s));
         FQ(hipGetLastError());
     }

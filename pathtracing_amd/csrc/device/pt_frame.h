@@ -52,12 +52,12 @@ struct SubBuffers {
 struct FastBuffers {
     float4 *rays_o;           // origin xyz, index bits of the triangle the ray starts on (never reported as a hit)
     float4 *rays_d;           // direction xyz, weight r1 (cos theta)
-    uint32_t *ray_slot;       // contribution slot = sample_in_pass * P + pixel
+    uint32_t *ray_slot;       // the ray's code: sample_in_pass * 64 + pixel of its 8x8 tile
     float4 *hits;             // t, u, v, triangle index bits (-1: miss)
     float4 *sp_pos;           // shading points (MAIN model): position xyz, triangle index bits
-    float4 *sp_nrm;           // normal xyz, slot bits
+    float4 *sp_nrm;           // normal xyz, queue index of the ray (bits)
     float4 *sp_base;          // r1 * 0.6 * txt * albedo / pi, unused
-    float4 *contrib;          // per slot: r1 * radiance of the sample ray
+    float4 *contrib;          // per queue entry: r1 * radiance of the sample ray
     uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2] shadow rays traced
     uint32_t *tile_base;      // per 8x8 tile in queue order: pixels with a primary hit before it (exclusive prefix sum; total at the end)
     unsigned long long *totals;   // [0] GI rays, [1] shadow rays of the view so far
