@@ -15,7 +15,7 @@ f = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=T
 rows = list(csv.DictReader(open(f)))
 with open(os.path.join(out, "stats.txt"), "w") as w:
     for r in rows:
-        line = f"{r['Name'][:70]:70s} calls {int(r['Calls']):6d} avg_us {float(r['AverageNs'])/1e3:10.1f} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} pct {float(r['Percentage']):6.2f}"
+        line = f"{r['Name'][:70]:70s} calls {int(r['Calls']):6d} avg_us {float(r['AverageNs'])/1e3:10.1f} min_us {float(r['MinNs'])/1e3:10.1f} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} pct {float(r['Percentage']):6.2f}"
         print(line); w.write(line + "\n")
 PY
 rm -rf "$OUT/trace"
