@@ -152,18 +152,28 @@ __global__ void __launch_bounds__(1024) k_tile_scan(FastBuffers Q, int tiles) {
 
 // One block = one 8x8 pixel tile x up to 64 samples of the pass (thread = pixel x sample lane,
 // four samples each): 4096 rays with nearby origins.  They are written to the queue sorted by
-// direction bin (counting sort in LDS), so that the 64 rays a wave of the closest-hit kernel
+// direction cell (counting sort in LDS), so that the 64 rays a wave of the closest-hit kernel
 // draws together start close to each other and point the same way.  Queue order inside the block is
 // free: the ray's code, (sample of the pass) * 64 + (pixel of the tile), travels with it.
-#define PT_GEN_AXIS_BITS 3                          // direction cells per axis = 1 << bits
-#define PT_GEN_BINS (1 << (3 * PT_GEN_AXIS_BITS))
+#define PT_GEN_CELL_BITS 6                          // direction cells per axis of the octahedral map = 1 << bits
+#define PT_GEN_BINS (1 << (2 * PT_GEN_CELL_BITS))
 __device__ __forceinline__ uint32_t dir_bin(float x, float y, float z) {
-    // cells of the cube [-1, 1]^3 that contains the unit sphere; about a sixth of them meet a hemisphere
-    const float n = (float)(1 << PT_GEN_AXIS_BITS), hi = n - 1.0f;
-    uint32_t qx = (uint32_t)fminf(fmaxf((x * 0.5f + 0.5f) * n, 0.0f), hi);
-    uint32_t qy = (uint32_t)fminf(fmaxf((y * 0.5f + 0.5f) * n, 0.0f), hi);
-    uint32_t qz = (uint32_t)fminf(fmaxf((z * 0.5f + 0.5f) * n, 0.0f), hi);
-    return (qx << (2 * PT_GEN_AXIS_BITS)) | (qy << PT_GEN_AXIS_BITS) | qz;
+    // The direction's place on the octahedral map of the sphere ([-1, 1]^2, every cell meets the sphere: a grid over the
+    // cube around the sphere wastes five cells in six), cells numbered along a Z curve so that the 64 rays a wave draws
+    // -- a run of 30-odd cells at the ~2 rays a cell holds -- point into one small patch of directions.
+    // 64 x 64 cells: closest-hit kernel +2.4 % over 8 x 8 x 8 cube cells in x-major order; 8 x 8 octahedral cells -4 %.
+    const float k = 1.0f / (fabsf(x) + fabsf(y) + fabsf(z));
+    float u = x * k, v = y * k;
+    if (z < 0.0f) {
+        const float uu = (1.0f - fabsf(v)) * (u >= 0.0f ? 1.0f : -1.0f), vv = (1.0f - fabsf(u)) * (v >= 0.0f ? 1.0f : -1.0f);
+        u = uu; v = vv;
+    }
+    const float n = (float)(1 << PT_GEN_CELL_BITS), hi = n - 1.0f;
+    const uint32_t qu = (uint32_t)fminf(fmaxf((u * 0.5f + 0.5f) * n, 0.0f), hi), qv = (uint32_t)fminf(fmaxf((v * 0.5f + 0.5f) * n, 0.0f), hi);
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 0; b < PT_GEN_CELL_BITS; b++) m |= (((qu >> b) & 1u) << (2 * b + 1)) | (((qv >> b) & 1u) << (2 * b));
+    return m;
 }
 
 __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, FrameBuffers F, FastBuffers Q, int s0, int nb, int groups) {
