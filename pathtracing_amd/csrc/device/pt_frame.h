@@ -84,7 +84,7 @@ int hemisphere_samples(uint32_t seed, uint32_t view, uint32_t pixel, int n, doub
 #define PT_TRACE_WAVES (256 * 32)   // waves of a trace launch: enough to fill every CU; surplus waves find the queue empty
 // Rays of one GI pass (one launch of every stage).  Larger passes amortise the ramp and the tail of the persistent
 // traversal launch and put more samples of a tile next to each other in the sorted queue: 16 Mi -> 64 Mi rays per
-// pass is +2.3 % whole-job on the 1 024-spp benchmark (128 Mi: another +0.3 %); the queues of a 64 Mi-ray pass
+// pass is +2.3 % whole-job on the 1 024-spp benchmark (128 Mi: another +0.3 to +0.8 %, 256 Mi: nothing more); the queues of a 64 Mi-ray pass
 // take 11 GB.  PT_TUNE_PASS_RAYS overrides it (tests use a small value to force several passes).
 #define PT_FAST_RAYS_PER_PASS (64u << 20)
 typedef int (*PtAllocFn)(void *ctx, size_t bytes, void **out);
