@@ -10,6 +10,7 @@
 //                   contribution; MAIN model: compacts hits into a shading-point queue
 //   k_shadow_gi     MAIN model: any-hit traversal towards every light (same machinery)
 //   k_gi_sum        ordered per-pixel sum of the pass's contributions (fp64)
+//   k_shade_sum_omp mainOMP model: the two stages before in one kernel (the contributions stay in LDS)
 //
 // A contribution is stored at its ray's place in the queue (streamed, not scattered) and carries the
 // ray's (sample, pixel) code; the summing block of a tile sorts them by that code in LDS and adds each
@@ -398,54 +399,59 @@ __device__ __forceinline__ void light_f(const float4 *lights, int k, float hx, f
     }
 }
 
+// r1 * castRay(sample ray, depth -1) of the mainOMP model (mainOMP.cpp:55-62,74-75: every light counts as visible;
+// txt * albedo * direct / pi) for queue entry r with hit record h; 0 on a miss.
+__device__ __forceinline__ float4 omp_contribution(const DevScene &S, const FastBuffers &Q, uint32_t r, float4 h) {
+    const int tri = __float_as_int(h.w);
+    if (tri < 0) return make_float4(0.f, 0.f, 0.f, 0.f);           // castRay returns 0 on a miss at depth -1
+    const float4 o = Q.rays_o[r], d = Q.rays_d[r];
+    float ar, ag, ab;
+    const SurfF sf = surface_f(S, tri, h.y, h.z, ar, ag, ab);
+    ar *= sf.tr; ag *= sf.tg; ab *= sf.tb;
+    const float hx = o.x + h.x * d.x + 0.0001f * sf.nx, hy = o.y + h.x * d.y + 0.0001f * sf.ny, hz = o.z + h.x * d.z + 0.0001f * sf.nz;
+    float dr = 0, dg = 0, db = 0;
+    for (int k = 0; k < S.n_light; k++) {
+        float lx, ly, lz, dis, sr, sg, sb;
+        light_f(S.lightsF, k, hx, hy, hz, lx, ly, lz, dis, sr, sg, sb);
+        const float c = fmaxf(0.0f, lx * sf.nx + ly * sf.ny + lz * sf.nz);
+        dr += c * sr; dg += c * sg; db += c * sb;
+    }
+    const float k = fabsf(d.w) * (1.0f / 3.14159265358979f);
+    return make_float4(k * ar * dr, k * ag * dg, k * ab * db, 0.f);
+}
+
 template <int MODEL>
 __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBuffers Q) {
     uint32_t r = blockIdx.x * PT_APPEND_BLOCK + threadIdx.x;
     bool in_range = r < Q.counts[0];
     bool hit = false;
     float4 sp_pos, sp_nrm, sp_base;
-    if (in_range) {
+    if (in_range && MODEL == PT_MODEL_OMP) {
+        Q.contrib[r] = omp_contribution(S, Q, r, Q.hits[r]);
+    } else if (in_range) {
         float4 h = Q.hits[r];
         int tri = __float_as_int(h.w);
         if (tri < 0) {
             Q.contrib[r] = make_float4(0.f, 0.f, 0.f, 0.f);        // castRay returns 0 on a miss at depth -1
         } else {
-            float4 o = Q.rays_o[r], d = Q.rays_d[r];
+            float4 d = Q.rays_d[r];
             float ar, ag, ab;
             SurfF sf = surface_f(S, tri, h.y, h.z, ar, ag, ab);
             ar *= sf.tr; ag *= sf.tg; ab *= sf.tb;
-            float hx, hy, hz;
-            if (MODEL == PT_MODEL_OMP) {
-                hx = o.x + h.x * d.x + 0.0001f * sf.nx; hy = o.y + h.x * d.y + 0.0001f * sf.ny; hz = o.z + h.x * d.z + 0.0001f * sf.nz;
-            } else {
-                // Shadow rays start here, 1e-4 off the surface (main.cpp:50), and that step has to survive: o + t d in fp32
-                // is off by t * 2^-24, more than 1e-4 for a ray a few thousand units long, and puts the point behind a
-                // second triangle lying in the same plane (two-sided leaves are modelled that way), which then shadows it.
-                // The point is taken from the triangle instead, v0 + u e1 + v e2 in fp64, and rounded once.
-                const double *T9 = S.triGeo + (size_t)tri * 9;
-                const double bu = (double)h.y, bv = (double)h.z;
-                hx = (float)(T9[0] + bu * T9[3] + bv * T9[6] + 1e-4 * (double)sf.nx);
-                hy = (float)(T9[1] + bu * T9[4] + bv * T9[7] + 1e-4 * (double)sf.ny);
-                hz = (float)(T9[2] + bu * T9[5] + bv * T9[8] + 1e-4 * (double)sf.nz);
-            }
-            if (MODEL == PT_MODEL_OMP) {
-                // mainOMP.cpp:55-62,74-75: every light is visible; r1 * txt*albedo*direct/pi
-                float dr = 0, dg = 0, db = 0;
-                for (int k = 0; k < S.n_light; k++) {
-                    float lx, ly, lz, dis, sr, sg, sb;
-                    light_f(S.lightsF, k, hx, hy, hz, lx, ly, lz, dis, sr, sg, sb);
-                    float c = fmaxf(0.0f, lx * sf.nx + ly * sf.ny + lz * sf.nz);
-                    dr += c * sr; dg += c * sg; db += c * sb;
-                }
-                float k = fabsf(d.w) * (1.0f / 3.14159265358979f);
-                Q.contrib[r] = make_float4(k * ar * dr, k * ag * dg, k * ab * db, 0.f);
-            } else {
-                hit = true;
-                float k = fabsf(d.w) * 0.6f * (1.0f / 3.14159265358979f);            // main.cpp:77 with ref = 0
-                sp_pos = make_float4(hx, hy, hz, __int_as_float(tri));
-                sp_nrm = make_float4(sf.nx, sf.ny, sf.nz, __uint_as_float(r));
-                sp_base = make_float4(k * ar, k * ag, k * ab, 0.f);
-            }
+            // Shadow rays start 1e-4 off the surface (main.cpp:50), and that step has to survive: o + t d in fp32
+            // is off by t * 2^-24, more than 1e-4 for a ray a few thousand units long, and puts the point behind a
+            // second triangle lying in the same plane (two-sided leaves are modelled that way), which then shadows it.
+            // The point is taken from the triangle instead, v0 + u e1 + v e2 in fp64, and rounded once.
+            const double *T9 = S.triGeo + (size_t)tri * 9;
+            const double bu = (double)h.y, bv = (double)h.z;
+            const float hx = (float)(T9[0] + bu * T9[3] + bv * T9[6] + 1e-4 * (double)sf.nx);
+            const float hy = (float)(T9[1] + bu * T9[4] + bv * T9[7] + 1e-4 * (double)sf.ny);
+            const float hz = (float)(T9[2] + bu * T9[5] + bv * T9[8] + 1e-4 * (double)sf.nz);
+            hit = true;
+            float k = fabsf(d.w) * 0.6f * (1.0f / 3.14159265358979f);            // main.cpp:77 with ref = 0
+            sp_pos = make_float4(hx, hy, hz, __int_as_float(tri));
+            sp_nrm = make_float4(sf.nx, sf.ny, sf.nz, __uint_as_float(r));
+            sp_base = make_float4(k * ar, k * ag, k * ab, 0.f);
         }
     }
     if (MODEL == PT_MODEL_MAIN) {
@@ -557,6 +563,42 @@ __global__ void __launch_bounds__(PT_SUM_THREADS) k_gi_sum(FrameBuffers F, FastB
         for (uint32_t k = tid; k < n; k += PT_SUM_THREADS) {
             const float4 c = Q.contrib[base + k];
             const uint32_t at = Q.ray_slot[base + k] - (uint32_t)g0 * 64u;
+            cr[at] = c.x; cg[at] = c.y; cb[at] = c.z;
+        }
+        __syncthreads();
+        if (shot)
+            for (int s = 0; s < gs; s++) { ax += (double)cr[s * 64 + tid]; ay += (double)cg[s * 64 + tid]; az += (double)cb[s * 64 + tid]; }
+        __syncthreads();
+    }
+    if (mine) { F.gi_acc[3 * p] = ax; F.gi_acc[3 * p + 1] = ay; F.gi_acc[3 * p + 2] = az; }
+}
+
+// The two stages above in one kernel for the mainOMP model, whose contribution needs no shadow ray: the block of a tile
+// shades the tile's rays itself and drops the results straight into LDS, so the contributions never travel to device
+// memory and back (32 bytes per ray) and one launch per pass goes.
+#define PT_FUSED_THREADS 1024
+__global__ void __launch_bounds__(PT_FUSED_THREADS) k_shade_sum_omp(DevScene S, FrameBuffers F, FastBuffers Q, int size, int nb, int first_batch) {
+    __shared__ float cr[64 * 64], cg[64 * 64], cb[64 * 64];
+    const int tid = threadIdx.x, qtile = blockIdx.x;
+    if (qtile == 0 && tid == 0) {
+        Q.totals[0] += Q.counts[0];
+        Q.totals[1] += Q.counts[2];
+    }
+    const int tile = ordered_tile(qtile, size);
+    const uint32_t t0 = Q.tile_base[qtile], valid = Q.tile_base[qtile + 1] - t0;
+    int i, j;
+    const bool mine = tid < 64 && tile_pixel_f(tile * 64 + tid, size, i, j);
+    const size_t p = mine ? (size_t)i * size + j : 0;
+    double ax = 0, ay = 0, az = 0;
+    if (mine && !first_batch) { ax = F.gi_acc[3 * p]; ay = F.gi_acc[3 * p + 1]; az = F.gi_acc[3 * p + 2]; }
+    const bool shot = mine && !(F.ghit[3 * p] == -99999);
+    for (int g0 = 0; g0 < nb && valid; g0 += 64) {
+        const int gs = nb - g0 < 64 ? nb - g0 : 64;
+        const uint32_t base = t0 * (uint32_t)nb + valid * (uint32_t)g0, n = valid * (uint32_t)gs;
+        for (uint32_t k = tid; k < n; k += PT_FUSED_THREADS) {
+            const uint32_t r = base + k;
+            const float4 c = omp_contribution(S, Q, r, Q.hits[r]);
+            const uint32_t at = Q.ray_slot[r] - (uint32_t)g0 * 64u;
             cr[at] = c.x; cg[at] = c.y; cb[at] = c.z;
         }
         __syncthreads();
@@ -710,6 +752,13 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(sblocks), dim3(PT_APPEND_BLOCK), (size_t)tune.shade_lds, s, S, Q);
             hipLaunchKernelGGL(k_shadow_gi, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
         } else {
+            static const bool fused = !(getenv("PT_TUNE_FUSED_SUM") && atoi(getenv("PT_TUNE_FUSED_SUM")) == 0);
+            if (fused) {
+                hipLaunchKernelGGL(k_shade_sum_omp, dim3((unsigned)(tthreads / 64)), dim3(PT_FUSED_THREADS), 0, s, S, F, Q, V.size, nb, s0 == 0);
+                FQ(hipEventRecord(events[4 * pass + 3], s));
+                FQ(hipGetLastError());
+                continue;
+            }
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_OMP>, dim3(sblocks), dim3(PT_APPEND_BLOCK), (size_t)tune.shade_lds, s, S, Q);
         }
         hipLaunchKernelGGL(k_gi_sum, dim3((unsigned)(tthreads / 64)), dim3(PT_SUM_THREADS), 0, s, F, Q, V.size, nb, s0 == 0);
