@@ -11,7 +11,8 @@ struct RefineParams {
     bool rebuild = true;        // build the whole fp32 tree from the triangles (false: keep the host tree, subdivide its leaves)
     float ct = 1.0f;            // cost of one traversal step
     float ci = 1.2f;            // cost of one triangle test
-    float empty_bonus = 0.8f;   // factor on splits that cut off empty space
+    float empty_bonus = 1.0f;   // factor on splits that cut off empty space (0.8 was 5 % slower on the atrium, 17 % on car)
+    bool clip = true;           // split clipping: a triangle's bounds in a child are those of the part of it inside the child
     int leaf_keep = 2;          // leaves with at most this many triangles are left alone
     int max_depth = 56;         // depth bound, counted from the root of the host tree
 };

@@ -39,8 +39,28 @@ inline float area(const Box3 &b) {
     return 2.0f * (x * y + y * z + z * x);
 }
 
+// A triangle as a node of the build sees it: its index and the bounds of the part of it that lies inside the node's box.
+struct Ref { int32_t tri; Box3 b; };
+
 // A subtree put aside by the top of the build, to be built by a worker thread.
-struct Job { uint32_t slot; Box3 box; std::vector<int32_t> ids; int depth; };
+struct Job { uint32_t slot; Box3 box; std::vector<Ref> ids; int depth; };
+
+// Sutherland-Hodgman: the part of a convex polygon on one side of an axis-aligned plane.
+inline int clip_plane(const double (*in)[3], int n, int axis, double plane, bool keep_above, double (*out)[3]) {
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const double *a = in[i], *b = in[(i + 1) % n];
+        const bool ia = keep_above ? a[axis] >= plane : a[axis] <= plane, ib = keep_above ? b[axis] >= plane : b[axis] <= plane;
+        if (ia) { for (int k = 0; k < 3; k++) out[m][k] = a[k]; m++; }
+        if (ia != ib) {
+            const double t = (plane - a[axis]) / (b[axis] - a[axis]);
+            for (int k = 0; k < 3; k++) out[m][k] = a[k] + t * (b[k] - a[k]);
+            out[m][axis] = plane;
+            m++;
+        }
+    }
+    return m;
+}
 
 struct Builder {
     const PtSceneDesc *d;
@@ -81,8 +101,56 @@ struct Builder {
         }
     }
 
+    // The allowance for the kernel's fp32 arithmetic (it intersects v0 + e1, v0 + e2 rounded to fp32): a few ulps of the
+    // largest coordinate involved.
+    static float slack(float lo, float hi) { return std::max(std::fabs(lo), std::fabs(hi)) * 4.8e-7f + 1e-30f; }
+
+    // Bounds of the part of triangle `t` inside `box` ("split clipping": the triangle itself is cut by the box, in
+    // fp64, not its bounding box -- a slanted triangle's bounding box reaches into cells the triangle never enters, and
+    // every such cell would list it and test it).  The box is widened by the fp32 allowance before the cut and the
+    // result widened again, so a cell never loses a triangle that the kernel's arithmetic could still hit inside it.
+    // False: no part of the triangle is inside.
+    bool clipped_bounds(int32_t t, const Box3 &box, Box3 &out) const {
+        double poly[2][12][3];
+        int n = 3, cur = 0;
+        for (int c = 0; c < 3; c++) {
+            const double *v = d->vert + 3 * (size_t)d->tri_vi[3 * (size_t)t + c];
+            for (int k = 0; k < 3; k++) poly[0][c][k] = v[k];
+        }
+        for (int k = 0; k < 3 && n; k++) {
+            const float m = slack(box.lo[k], box.hi[k]);
+            n = clip_plane(poly[cur], n, k, (double)box.lo[k] - (double)m, true, poly[cur ^ 1]); cur ^= 1;
+            if (!n) break;
+            n = clip_plane(poly[cur], n, k, (double)box.hi[k] + (double)m, false, poly[cur ^ 1]); cur ^= 1;
+        }
+        if (!n) return false;
+        for (int k = 0; k < 3; k++) {
+            double lo = poly[cur][0][k], hi = lo;
+            for (int i = 1; i < n; i++) { lo = std::min(lo, poly[cur][i][k]); hi = std::max(hi, poly[cur][i][k]); }
+            float fl = std::nextafter((float)lo, -INFINITY), fh = std::nextafter((float)hi, INFINITY);
+            const float m = slack(fl, fh);
+            out.lo[k] = std::max(fl - m, box.lo[k]);
+            out.hi[k] = std::min(fh + m, box.hi[k]);
+            if (out.lo[k] > out.hi[k]) { out.lo[k] = out.hi[k] = std::min(std::max(fl, box.lo[k]), box.hi[k]); }
+        }
+        return true;
+    }
+
+    // The triangles `tris` as references inside `box` (bounding boxes cut by the box; the exact cut comes with the splits).
+    std::vector<Ref> make_refs(const int32_t *tris, size_t n, const Box3 &box) const {
+        std::vector<Ref> out(n);
+        for (size_t i = 0; i < n; i++) {
+            out[i].tri = tris[i];
+            for (int k = 0; k < 3; k++) {
+                out[i].b.lo[k] = std::max(tbox[tris[i]].lo[k], box.lo[k]);
+                out[i].b.hi[k] = std::min(tbox[tris[i]].hi[k], box.hi[k]);
+            }
+        }
+        return out;
+    }
+
     // Emit node `slot` for the triangles `ids` inside `box`; children go to fresh adjacent slots.
-    void build(uint32_t slot, const Box3 &box, std::vector<int32_t> &ids, int depth) {
+    void build(uint32_t slot, const Box3 &box, std::vector<Ref> &ids, int depth) {
         const size_t n = ids.size();
         if (jobs && depth == job_depth && n > 4096) {
             jobs->push_back(Job{slot, box, std::move(ids), depth});
@@ -97,8 +165,8 @@ struct Builder {
                 const float blo = box.lo[a], bhi = box.hi[a];
                 if (!(bhi > blo)) continue;
                 for (size_t i = 0; i < n; i++) {
-                    los[i] = std::max(tbox[ids[i]].lo[a], blo);
-                    his[i] = std::min(tbox[ids[i]].hi[a], bhi);
+                    los[i] = std::max(ids[i].b.lo[a], blo);
+                    his[i] = std::min(ids[i].b.hi[a], bhi);
                 }
                 std::sort(los.begin(), los.end());
                 std::sort(his.begin(), his.end());
@@ -128,21 +196,34 @@ struct Builder {
         if (best_axis < 0) {
             o.split = 0; o.link = 0xFFFFFFFFu;
             o.first = (uint32_t)refs.size(); o.count = (uint32_t)n;
-            refs.insert(refs.end(), ids.begin(), ids.end());
+            for (const Ref &r : ids) refs.push_back(r.tri);
             st.leaves++; st.leaf_refs += n;
             st.max_leaf = std::max<uint64_t>(st.max_leaf, n);
             st.max_depth = std::max(st.max_depth, depth);
             return;
         }
-        std::vector<int32_t> L, R;
-        for (int32_t t : ids) {
-            float lo = std::max(tbox[t].lo[best_axis], box.lo[best_axis]), hi = std::min(tbox[t].hi[best_axis], box.hi[best_axis]);
+        Box3 lb = box, rb = box;
+        lb.hi[best_axis] = best_plane; rb.lo[best_axis] = best_plane;
+        std::vector<Ref> L, R;
+        for (const Ref &t : ids) {
+            const float lo = std::max(t.b.lo[best_axis], box.lo[best_axis]), hi = std::min(t.b.hi[best_axis], box.hi[best_axis]);
             bool l = lo < best_plane, r = hi > best_plane;
             if (!l && !r) l = true;                       // flat in the plane
-            if (l) L.push_back(t);
-            if (r) R.push_back(t);
+            if (l && r && prm.clip) {
+                // on both sides by its bounds: each child gets the bounds of the part that is really inside it, or nothing
+                Ref a = t, b = t;
+                const bool in_l = clipped_bounds(t.tri, lb, a.b), in_r = clipped_bounds(t.tri, rb, b.b);
+                if (in_l || in_r) {
+                    if (in_l) L.push_back(a);
+                    if (in_r) R.push_back(b);
+                    continue;
+                }
+            }
+            Ref c = t;
+            if (l) { c.b.hi[best_axis] = std::min(c.b.hi[best_axis], best_plane); L.push_back(c); c = t; }
+            if (r) { c.b.lo[best_axis] = std::max(c.b.lo[best_axis], best_plane); R.push_back(c); }
         }
-        std::vector<int32_t>().swap(ids);
+        std::vector<Ref>().swap(ids);
         uint32_t left = (uint32_t)nodes.size();
         nodes.push_back(NodeF{});
         nodes.push_back(NodeF{});
@@ -151,8 +232,6 @@ struct Builder {
         o2.link = left | ((uint32_t)best_axis << 30);
         o2.first = (uint32_t)refs.size(); o2.count = 0;
         st.new_nodes += 2;
-        Box3 lb = box, rb = box;
-        lb.hi[best_axis] = best_plane; rb.lo[best_axis] = best_plane;
         build(left, lb, L, depth + 1);
         build(left + 1, rb, R, depth + 1);
     }
@@ -240,10 +319,11 @@ RefineStats refine_tree(const PtSceneDesc *d, const RefineParams &prm, std::vect
     if (prm.rebuild) {
         // Experiment: ignore the host tree and build the whole tree with the sweep above.
         nodes.assign(1, NodeF{});
-        std::vector<int32_t> all(d->n_tri);
-        for (uint32_t t = 0; t < d->n_tri; t++) all[t] = (int32_t)t;
+        std::vector<int32_t> every(d->n_tri);
+        for (uint32_t t = 0; t < d->n_tri; t++) every[t] = (int32_t)t;
         Box3 box;
         for (int c = 0; c < 3; c++) { box.lo[c] = (float)d->nodes[0].lo[c]; box.hi[c] = (float)d->nodes[0].hi[c]; }
+        std::vector<Ref> all = b.make_refs(every.data(), every.size(), box);
         std::vector<Job> jobs;
         b.jobs = &jobs; b.job_depth = 6;
         b.build(0, box, all, 0);
@@ -265,13 +345,13 @@ RefineStats refine_tree(const PtSceneDesc *d, const RefineParams &prm, std::vect
             b.st.interior_refs += (uint64_t)n.count;
             continue;
         }
-        std::vector<int32_t> ids(d->refs + n.first, d->refs + n.first + n.count);
         Box3 box;
         for (int c = 0; c < 3; c++) { box.lo[c] = (float)n.lo[c]; box.hi[c] = (float)n.hi[c]; }
+        std::vector<Ref> ids = b.make_refs(d->refs + n.first, (size_t)n.count, box);
         if (!prm.enable) {
             NodeF &o = nodes[k];
             o.split = 0; o.link = 0xFFFFFFFFu; o.first = (uint32_t)refs.size(); o.count = (uint32_t)ids.size();
-            refs.insert(refs.end(), ids.begin(), ids.end());
+            refs.insert(refs.end(), d->refs + n.first, d->refs + n.first + n.count);
             b.st.leaves++; b.st.leaf_refs += ids.size();
             b.st.max_leaf = std::max<uint64_t>(b.st.max_leaf, ids.size());
             b.st.max_depth = std::max(b.st.max_depth, depth[k]);
