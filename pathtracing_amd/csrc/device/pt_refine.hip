@@ -16,7 +16,7 @@
 //   0  the host tree as it is;
 //   1  the host tree, every leaf with more than a few triangles subdivided;
 //   2  (default) a tree built from the triangles: surface-area-heuristic sweep over
-//      the triangles' clipped bounds on all three axes, empty-space bonus.
+//      the triangles' bounds on all three axes, with split clipping.
 // Measured on MI355X with the closest-hit kernel as it was when the variants were
 // compared, 64 spp: atrium-262k 0.91 / 1.69 / 2.6 Grays/s, car 2.9 / 4.8 / 7.2 Grays/s.
 // The build runs on up to 16 host threads (subtrees below a fixed depth are
