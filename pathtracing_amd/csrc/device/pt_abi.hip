@@ -251,7 +251,6 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
     if (const char *e = getenv("PT_TUNE_EMPTY")) rp.empty_bonus = (float)atof(e);
     if (const char *e = getenv("PT_TUNE_CLIP")) rp.clip = atoi(e) != 0;
     if (const char *e = getenv("PT_TUNE_DEPTH")) { int k = atoi(e); if (k >= 8 && k <= 60) rp.max_depth = k; }
-    if (const char *e = getenv("PT_TUNE_DEPTH")) { int k = atoi(e); if (k >= 8 && k <= 60) rp.max_depth = k; }
     {
         const RefineStats r = refine_tree(d, rp, nf, frefs);    // member by member: a struct copy need not keep H's zeroed padding
         H.refine.nodes = r.nodes; H.refine.refs = r.refs; H.refine.leaves = r.leaves; H.refine.leaf_refs = r.leaf_refs;
