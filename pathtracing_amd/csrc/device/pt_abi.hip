@@ -69,7 +69,7 @@ struct Workspace {
 
 // Header of a scene slab (the one device allocation that holds every immutable array of a scene).
 struct SlabHeader {
-    char magic[8];                    // "PTSLAB01"
+    char magic[8];                    // "PTSLAB02"
     uint64_t total_bytes;             // header + arrays
     DevScene S;                       // pointer fields of PT_SLAB_POINTERS: byte offsets from the slab's start; scratch pointers null
     RefineStats refine;
@@ -268,6 +268,8 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
         for (int k = 0; k < 3; k++) { o[k] = a[k]; o[3 + k] = b[k] - a[k]; o[6 + k] = c[k] - a[k]; }
     };
     for (uint32_t r = 0; r < d->n_ref; r++) tri9(d->refs[r], &rt[(size_t)r * 9]);
+    const std::vector<uint4> quads = quad_records(nf);
+    if ((uint64_t)quads.size() * 16u >= (1ull << 32)) return fail(PT_ERR_LIMIT, "kd-tree too large for 32-bit byte offsets (quad records)");
     for (NodeF &n : nf) n = encode_node(n);
     // ---- per-triangle geometry by triangle index (origin-triangle tests of the GI fast path) ----
     std::vector<double> tgeo((size_t)d->n_tri * 9);
@@ -302,6 +304,8 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
     B.add(na.data(), na.size(), &DevScene::nodeA);
     B.add(nbox.data(), nbox.size(), &DevScene::nodeBox);
     B.add(nf.data(), nf.size(), &DevScene::nodeF);
+    B.add(quads.data(), quads.size(), &DevScene::quadF);
+    S.has_quads = quads.empty() ? 0 : 1;
     B.add(rt.data(), rt.size(), &DevScene::refTri);
     B.add(rtf.data(), rtf.size(), &DevScene::refTriF);
     B.add(tgeo.data(), tgeo.size(), &DevScene::triGeo);
@@ -360,12 +364,13 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
         S.root_hi[k] = d->nodes[0].hi[k];
     }
     // sizes of the scratch every copy of the scene allocates for itself
-    S.ovf_depth = (uint32_t)H.refine.max_depth + 2u;
+    // a binary descent leaves at most one entry per level on the stack, a quad record up to three per two levels
+    S.ovf_depth = (uint32_t)H.refine.max_depth * 3u / 2u + 4u;
     // PT_TUNE_OVF_DEPTH: a smaller stack than the tree needs, for the test of the limit report
     if (const char *e = getenv("PT_TUNE_OVF_DEPTH")) { int k = atoi(e); if (k >= 1 && (uint32_t)k < S.ovf_depth) S.ovf_depth = (uint32_t)k; }
     S.ovf_waves = PT_TRACE_WAVES;
     S.ovf64_entries = (uint32_t)depth + 2u;
-    std::memcpy(H.magic, "PTSLAB01", 8);
+    std::memcpy(H.magic, "PTSLAB02", 8);
     H.total_bytes = B.bytes.size();
     H.check = header_check(H);
     std::memcpy(B.bytes.data(), &H, sizeof H);
@@ -373,7 +378,7 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
 }
 
 int check_slab_header(const SlabHeader &H, size_t bytes) {
-    if (std::memcmp(H.magic, "PTSLAB01", 8) != 0 || H.total_bytes != bytes || bytes < sizeof(SlabHeader) || H.check != header_check(H))
+    if (std::memcmp(H.magic, "PTSLAB02", 8) != 0 || H.total_bytes != bytes || bytes < sizeof(SlabHeader) || H.check != header_check(H))
         return fail(PT_ERR_INVALID, "not a scene slab of this library version, or damaged");
 #define X(f) if ((uintptr_t)H.S.f < sizeof(SlabHeader) || (uintptr_t)H.S.f >= bytes) return fail(PT_ERR_INVALID, "scene slab: array offset out of range");
     PT_SLAB_POINTERS(X)
@@ -1167,7 +1172,7 @@ int pt_trace_device(PtScene *sc, size_t n, const double *d_src, const double *d_
     if (!d_src || !d_dir || !d_tmin_in || !d_found || !d_mesh || !d_tri || !d_t || !d_u || !d_v)
         return fail(PT_ERR_INVALID, "pt_trace_device: null array");
     if (n > PT_STATIC_MAX_RAYS) return fail(PT_ERR_LIMIT, "pt_trace_device: more than 2^24 rays in one call");
-    if (sc->S.ovf_depth > PT_STATIC_DEPTH)
+    if ((uint32_t)sc->refine.max_depth + 2u > PT_STATIC_DEPTH)            // this path walks the binary records: one stack entry per level
         return fail(PT_ERR_LIMIT, "pt_trace_device: the scene's fp32 tree is deeper than the fixed scratch stack (62 levels)");
     std::lock_guard<std::mutex> lock(sc->busy);       // one scene, one stream; the fixed scratch array is per GPU (see the header)
     HIPCHK(hipSetDevice(sc->device));

@@ -22,6 +22,7 @@
 #include "pt_frame.h"
 #include "pt_persistent.h"
 #include "pt_trace_f32.h"
+#include "pt_trace_quad.h"
 #include "pt_vec.h"
 
 #pragma clang fp contract(fast)
@@ -291,16 +292,17 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
 #define PT_GEN_LDS_BYTES ((4096 + 64) * sizeof(float4) + 4096 * sizeof(uint32_t))
 
 // ---- stage 2: closest hit -------------------------------------------------------
-template <bool COUNT>
+// LS: LaneState (binary node records, pt_trace_f32.h) or LaneStateQ (quad records, pt_trace_quad.h); the same search.
+template <bool COUNT, class LS>
 struct ClosestPolicy {
     const DevScene &S;
     const FastBuffers &Q;
     const RootBox box;
     uint2 *stk;
     uint32_t slot_mask;
-    LaneState L;
+    LS L;
     uint32_t r, work[2];
-    __device__ __forceinline__ void census() { if (COUNT) { work[0]++; work[1] += (L.tend - L.toff) / 48u; } }
+    __device__ __forceinline__ void census() { if (COUNT) { work[0]++; work[1] += tris_here(L); } }
     __device__ __forceinline__ bool step(bool active) {
         const bool done = lane_turn<false, COUNT>(L, S, stk, slot_mask, work, active);
         if (done) Q.hits[r] = make_float4(L.tmin, L.hu, L.hv, __int_as_float(L.htri));
@@ -316,10 +318,10 @@ struct ClosestPolicy {
     }
 };
 
-template <bool COUNT>
+template <bool COUNT, class LS>
 __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
     extern __shared__ uint2 stack[];            // (slot_mask + 1) * 64 entries
-    ClosestPolicy<COUNT> P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
+    ClosestPolicy<COUNT, LS> P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
     P.work[0] = P.work[1] = 0;
     persistent_loop(P, Q.counts[0], Q.heads, chunk, refill_min);
     if (COUNT) {
@@ -462,13 +464,14 @@ __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBu
 
 // ---- stage 4 (MAIN model): shadow rays of the GI hits ------------------------------
 // One work item = one shading point; its lights are visited in order by the same lane.
+template <class LS>
 struct ShadowPolicy {
     const DevScene &S;
     const FastBuffers &Q;
     const RootBox box;
     uint2 *stk;
     uint32_t slot_mask;
-    LaneState L;
+    LS L;
     // Little is kept per lane: the point is the origin of the running ray (L.ox..), its triangle is
     // L.skip, and the normal / base colour are re-read from the queue when a light is chosen or the
     // point completes.
@@ -524,9 +527,10 @@ struct ShadowPolicy {
     }
 };
 
+template <class LS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) k_shadow_gi(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
     extern __shared__ uint2 stack[];
-    ShadowPolicy P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
+    ShadowPolicy<LS> P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
     P.shadow = 0; P.fresh = false;
     persistent_loop(P, Q.counts[1], Q.heads + PT_HEAD_WORDS, chunk, refill_min);
     uint32_t n = P.shadow;
@@ -610,12 +614,13 @@ __global__ void __launch_bounds__(PT_FUSED_THREADS) k_shade_sum_omp(DevScene S, 
 }
 
 // ---- raw queries for tests: fp64 in/out around the fp32 traversal -------------------
+template <class LS>
 struct RawPolicy {
     const DevScene &S;
     const RootBox box;
     uint2 *stk;
     uint32_t slot_mask;
-    LaneState L;
+    LS L;
     const double *src, *dir, *tmin_in;
     int32_t *found, *tri;
     double *t, *u, *v;
@@ -640,11 +645,12 @@ struct RawPolicy {
     }
 };
 
+template <class LS>
 __global__ void __launch_bounds__(64) k_trace_fast_f64io(DevScene S, uint32_t n, uint32_t *head, const double *src, const double *dir,
                                                          const double *tmin_in, int32_t *found, int32_t *tri, double *t,
                                                          double *u, double *v, uint32_t slot_mask) {
     extern __shared__ uint2 stack[];
-    RawPolicy P{S, root_box(S), stack + (threadIdx.x & 63), slot_mask, LaneState(), src, dir, tmin_in, found, tri, t, u, v, 0};
+    RawPolicy<LS> P{S, root_box(S), stack + (threadIdx.x & 63), slot_mask, LS(), src, dir, tmin_in, found, tri, t, u, v, 0};
     persistent_loop(P, n, head, 64u, 1);
 }
 
@@ -689,6 +695,11 @@ static TraceTune trace_tune() {
         return v;
     }();
     return t;
+}
+
+static bool use_quads() {
+    static const bool on = !(getenv("PT_TUNE_QUAD") && atoi(getenv("PT_TUNE_QUAD")) == 0);
+    return on;
 }
 
 int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers QQ[2], int nsamples, int batch,
@@ -743,14 +754,24 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         unsigned tblocks = qblocks < (unsigned)tune.waves ? qblocks : (unsigned)tune.waves;
         size_t lds = (size_t)tune.slots * 64 * sizeof(uint2);
         const uint32_t chunk = (uint32_t)tune.chunk;
-        if (work)
-            hipLaunchKernelGGL(k_trace_closest<true>, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
+        // quad records (two tree levels per request) whenever the tree has them; PT_TUNE_QUAD=0 walks the binary records
+        const bool quads = S.has_quads && use_quads();
+        const uint32_t smask = (uint32_t)tune.slots - 1u;
+        if (quads && work)
+            hipLaunchKernelGGL((k_trace_closest<true, LaneStateQ>), dim3(tblocks), dim3(64), lds, s, S, Q, smask, tune.refill, chunk);
+        else if (quads)
+            hipLaunchKernelGGL((k_trace_closest<false, LaneStateQ>), dim3(tblocks), dim3(64), lds, s, S, Q, smask, tune.refill, chunk);
+        else if (work)
+            hipLaunchKernelGGL((k_trace_closest<true, LaneState>), dim3(tblocks), dim3(64), lds, s, S, Q, smask, tune.refill, chunk);
         else
-            hipLaunchKernelGGL(k_trace_closest<false>, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
+            hipLaunchKernelGGL((k_trace_closest<false, LaneState>), dim3(tblocks), dim3(64), lds, s, S, Q, smask, tune.refill, chunk);
         FQ(hipEventRecord(events[4 * pass + 2], s));
         if (V.model == PT_MODEL_MAIN) {
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(sblocks), dim3(PT_APPEND_BLOCK), (size_t)tune.shade_lds, s, S, Q);
-            hipLaunchKernelGGL(k_shadow_gi, dim3(tblocks), dim3(64), lds, s, S, Q, (uint32_t)tune.slots - 1u, tune.refill, chunk);
+            if (quads)
+                hipLaunchKernelGGL(k_shadow_gi<LaneStateQ>, dim3(tblocks), dim3(64), lds, s, S, Q, smask, tune.refill, chunk);
+            else
+                hipLaunchKernelGGL(k_shadow_gi<LaneState>, dim3(tblocks), dim3(64), lds, s, S, Q, smask, tune.refill, chunk);
         } else {
             static const bool fused = !(getenv("PT_TUNE_FUSED_SUM") && atoi(getenv("PT_TUNE_FUSED_SUM")) == 0);
             if (fused) {
@@ -815,7 +836,7 @@ __global__ void k_tri_to_mesh_local(DevScene S, uint32_t n, int32_t *tri, int32_
 int fast_trace_static(const DevScene &S0, int device, size_t n, const double *src, const double *dir, const double *tmin_in,
                       int32_t *found, int32_t *mesh, int32_t *tri, double *t, double *u, double *v, hipStream_t s) {
     if (device < 0 || device >= PT_STATIC_MAX_DEVICES || !g_scratch_ptr[device]) return PT_ERR_NO_DEVICE;
-    if (n > PT_STATIC_MAX_RAYS || S0.ovf_depth > PT_STATIC_DEPTH) return PT_ERR_LIMIT;
+    if (n > PT_STATIC_MAX_RAYS) return PT_ERR_LIMIT;              // the caller has checked the tree's depth against PT_STATIC_DEPTH
     unsigned char *base = g_scratch_ptr[device];
     DevScene S = S0;
     S.ovf = (uint2 *)(base + PT_STATIC_HEAD_BYTES);
@@ -825,7 +846,8 @@ int fast_trace_static(const DevScene &S0, int device, size_t n, const double *sr
     const TraceTune tune = trace_tune();
     unsigned blocks = (unsigned)((n + 63) / 64);
     if (blocks > PT_STATIC_WAVES) blocks = PT_STATIC_WAVES;
-    hipLaunchKernelGGL(k_trace_fast_f64io, dim3(blocks), dim3(64), (size_t)tune.slots * 64 * sizeof(uint2), s, S, (uint32_t)n,
+    // binary records here: one stack entry per tree level, which is what the fixed scratch is sized for
+    hipLaunchKernelGGL(k_trace_fast_f64io<LaneState>, dim3(blocks), dim3(64), (size_t)tune.slots * 64 * sizeof(uint2), s, S, (uint32_t)n,
                        (uint32_t *)base, src, dir, tmin_in, found, tri, t, u, v, (uint32_t)tune.slots - 1u);
     hipLaunchKernelGGL(k_tri_to_mesh_local, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, S, (uint32_t)n, tri, mesh);
     FQ(hipGetLastError());
@@ -843,8 +865,12 @@ int fast_trace(const DevScene &S, size_t n, const double *src, const double *dir
     unsigned blocks = (unsigned)((n + 63) / 64);
     if (blocks > (unsigned)tune.waves) blocks = (unsigned)tune.waves;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_trace_fast_f64io, dim3(blocks), dim3(64), (size_t)tune.slots * 64 * sizeof(uint2), s, S, (uint32_t)n, head,
-                           src, dir, tmin_in, found, tri, t, u, v, (uint32_t)tune.slots - 1u);
+        if (S.has_quads && use_quads())
+            hipLaunchKernelGGL(k_trace_fast_f64io<LaneStateQ>, dim3(blocks), dim3(64), (size_t)tune.slots * 64 * sizeof(uint2), s, S, (uint32_t)n, head,
+                               src, dir, tmin_in, found, tri, t, u, v, (uint32_t)tune.slots - 1u);
+        else
+            hipLaunchKernelGGL(k_trace_fast_f64io<LaneState>, dim3(blocks), dim3(64), (size_t)tune.slots * 64 * sizeof(uint2), s, S, (uint32_t)n, head,
+                               src, dir, tmin_in, found, tri, t, u, v, (uint32_t)tune.slots - 1u);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);

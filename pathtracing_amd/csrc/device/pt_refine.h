@@ -25,3 +25,7 @@ struct RefineStats {
 // nodes: the device node array (host nodes keep their indices, new nodes are
 // appended in adjacent pairs); refs: triangle indices in node order.
 RefineStats refine_tree(const PtSceneDesc *d, const RefineParams &prm, std::vector<NodeF> &nodes, std::vector<int32_t> &refs);
+
+// The built tree (as refine_tree leaves it) as quad records, two levels per record (layout: pt_trace_quad.h).
+// Empty when the tree keeps triangles in interior nodes, which quad records cannot express.
+std::vector<uint4> quad_records(const std::vector<NodeF> &nodes);

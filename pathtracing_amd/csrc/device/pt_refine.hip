@@ -364,3 +364,42 @@ RefineStats refine_tree(const PtSceneDesc *d, const RefineParams &prm, std::vect
     b.st.refs = refs.size();
     return b.st;
 }
+
+std::vector<uint4> quad_records(const std::vector<NodeF> &nodes) {
+    std::vector<uint4> q;
+    for (const NodeF &n : nodes)
+        if (n.link != 0xFFFFFFFFu && n.count != 0) return q;             // triangles in an interior node
+    const uint4 unused = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);              // an empty leaf; never referenced
+    auto leaf_record = [](const NodeF &n) { return make_uint4(n.first * 48u, (n.first + n.count) * 48u, 0u, 0xFFFFFFFFu); };
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    q.assign(4, unused);                                                  // the root's record, padded to a line
+    std::vector<std::pair<uint32_t, uint32_t>> todo;                      // (node, record to fill); depth first
+    todo.push_back({0u, 0u});
+    while (!todo.empty()) {
+        const auto [ni, slot] = todo.back();
+        todo.pop_back();
+        const NodeF n = nodes[ni];
+        if (n.link == 0xFFFFFFFFu) { q[slot] = leaf_record(n); continue; }
+        const uint32_t left = n.link & 0x3FFFFFFFu, base = (uint32_t)q.size();     // a multiple of four: 64-byte aligned
+        q.resize(q.size() + 4, unused);
+        uint32_t code[2];
+        float split[2];
+        for (int h = 1; h >= 0; h--) {                                    // right half first, so that the left subtree is laid out first
+            const NodeF c = nodes[left + (uint32_t)h];
+            if (c.link == 0xFFFFFFFFu) {
+                code[h] = 3u; split[h] = 0.f;
+                q[base + 2u * (uint32_t)h] = leaf_record(c);
+            } else {
+                code[h] = c.link >> 30; split[h] = c.split;
+                const uint32_t cl = c.link & 0x3FFFFFFFu;
+                todo.push_back({cl + 1u, base + 2u * (uint32_t)h + 1u});
+                todo.push_back({cl, base + 2u * (uint32_t)h});
+            }
+        }
+        q[slot] = make_uint4(bits(n.split), bits(split[0]), bits(split[1]), (base * 16u) | (code[1] << 4) | (code[0] << 2) | (n.link >> 30));
+    }
+    // every link must stay inside the array (the kernel follows them unchecked)
+    for (const uint4 &r : q)
+        if (r.w != 0xFFFFFFFFu && (uint64_t)(r.w & ~63u) + 64u > (uint64_t)q.size() * 16u) return std::vector<uint4>();
+    return q;
+}

@@ -44,6 +44,8 @@ struct DevScene {
     uint32_t ovf64_entries;    //   per lane for each of the PT_EXACT_WAVES blocks the fp64 kernels are launched with
     // ---- fp32 fast path ----
     const NodeF *nodeF;
+    const uint4 *quadF;        // the same tree as quad records (pt_trace_quad.h); has_quads: it exists
+    int32_t has_quads;
     const float4 *refTriF;     // 3 float4 per ref: (v0, id bits), (e2.x, e1.x, e2.y, e1.y), (e2.z, e1.z, 0, 0)
     uint2 *ovf;                // traversal overflow stack: [wave][entry][lane], ovf_depth entries per lane, ovf_waves waves
     uint32_t ovf_depth, ovf_waves;
@@ -77,7 +79,7 @@ struct DevScene {
 // from the slab's start, so a copy of the slab on another GPU (or in another process) becomes a scene by adding its
 // own base address -- no host preprocessing, no second build of the fp32 tree.
 #define PT_SLAB_POINTERS(X) \
-    X(nodeA) X(nodeBox) X(refTri) X(refId) X(nodeF) X(refTriF) X(triGeo) X(triNgF) X(tri_ni) X(tri_ti) X(tri_tm) X(tri_reft) \
+    X(nodeA) X(nodeBox) X(refTri) X(refId) X(nodeF) X(quadF) X(refTriF) X(triGeo) X(triNgF) X(tri_ni) X(tri_ti) X(tri_tm) X(tri_reft) \
     X(tri_mesh) X(tri_local) X(norm) X(uv) X(albedo) X(triShadeF) X(texels) X(tex_off) X(tex_rows) X(tex_cols) X(lights) X(lightsF)
 
 enum { PT_LIMIT_F32_STACK = 1, PT_LIMIT_F32_STEPS = 2, PT_LIMIT_F64_STACK = 4 };

@@ -61,6 +61,8 @@ __device__ __forceinline__ RootBox root_box(const DevScene &S) {
     return b;
 }
 
+__device__ __forceinline__ uint32_t tris_here(const LaneState &L) { return (L.tend - L.toff) / 48u; }
+
 __device__ __forceinline__ float sel3(uint32_t a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
 
 __device__ __forceinline__ void load_node(LaneState &L, const DevScene &S, uint32_t off) {
@@ -169,7 +171,7 @@ __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2
     if (runaway) atomicOr((unsigned int *)S.err, (unsigned int)PT_LIMIT_F32_STEPS);          // never seen; ends the ray so that the wave ends
     done = finished | exhausted | runaway;
     load_node(L, S, curr);
-    if (COUNT && !done) { work[0]++; work[1] += (L.tend - L.toff) / 48u; }
+    if (COUNT && !done) { work[0]++; work[1] += tris_here(L); }
     }
     return done;
 }

@@ -1,0 +1,141 @@
+// fp32 kd traversal over "quad" records: one 16-byte record holds an interior node's split plane AND the split planes
+// of its two children, so one request (what bounds the kernel) takes a ray down two levels of the tree.
+//
+// Quad record:  s0 | s1 | s2 | link        s0: the node's plane, s1 / s2: the left / right child's
+//   link = (byte offset of the group of four 16-byte records of the grandchildren, 64-byte aligned) | a2 << 4 | a1 << 2 | a0
+//   a0: the node's axis (0..2); a1, a2: the children's axes, 3 = that child is a leaf
+//   group: [left-left, left-right, right-left, right-right]; a leaf child's record sits in the first slot of its half
+// Leaf record:  tri_off | tri_end | 0 | 0xFFFFFFFF   (byte offsets into the 48-byte triangle records)
+// Everything else -- the triangle test, the ring stack with its overflow column, front-to-back order, both children on
+// equality -- is as in pt_trace_f32.h; the visiting order of the leaves is the same, so the results are the same bit for bit.
+#pragma once
+#include "pt_trace_f32.h"
+
+struct LaneStateQ {
+    float ox, oy, oz, ix, iy, iz;
+    f32x2 dtx, dty, dtz;
+    float tmin, ent, ext, hu, hv;
+    int htri, skip;
+    uint32_t top, cs, novf;
+    uint32_t n0, n1, n2, nlink;         // current record: quad (s0, s1, s2, link) or leaf (tri_off, tri_end, -, ~0)
+};
+
+__device__ __forceinline__ void load_quad(LaneStateQ &L, const DevScene &S, uint32_t off) {
+    const uint4 n = *(const uint4 *)((const char *)S.quadF + off);
+    L.n0 = n.x; L.n1 = n.y; L.n2 = n.z; L.nlink = n.w;
+}
+
+__device__ __forceinline__ bool lane_begin(LaneStateQ &L, const DevScene &S, const RootBox &b, float ox, float oy, float oz,
+                                             float dx, float dy, float dz, float tmax, int skip) {
+    L.ox = ox; L.oy = oy; L.oz = oz; L.dtx.x = dx; L.dty.x = dy; L.dtz.x = dz;
+    L.ix = __builtin_amdgcn_rcpf(dx); L.iy = __builtin_amdgcn_rcpf(dy); L.iz = __builtin_amdgcn_rcpf(dz);
+    float a0 = (b.lx - ox) * L.ix, a1 = (b.hx - ox) * L.ix;
+    float b0 = (b.ly - oy) * L.iy, b1 = (b.hy - oy) * L.iy;
+    float c0 = (b.lz - oz) * L.iz, c1 = (b.hz - oz) * L.iz;
+    L.ent = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+    L.ext = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tmax));
+    L.tmin = tmax; L.htri = -1; L.hu = 0; L.hv = 0; L.skip = skip;
+    L.top = 0; L.cs = 0; L.novf = 0;
+    if (!(L.ent <= L.ext)) return false;
+    load_quad(L, S, 0);
+    return true;
+}
+
+// Triangles of the record the lane stands on (0 for a quad): what the counting build of a kernel adds per arrival.
+__device__ __forceinline__ uint32_t tris_here(const LaneStateQ &L) { return L.nlink == 0xFFFFFFFFu ? (L.n1 - L.n0) / 48u : 0u; }
+
+// Push (node, ext) when `pred`: the ring keeps one slot free; when it is full its oldest entry moves to the overflow column.
+__device__ __forceinline__ void push_q(LaneStateQ &L, const DevScene &S, uint2 *stk, uint32_t slot_mask, bool pred, uint32_t node, float ext) {
+    if (pred) {
+        if ((L.cs & 0xFFu) == slot_mask) {
+            uint2 *ovf = overflow_column(S);
+            if (L.novf < S.ovf_depth) { ovf[(size_t)L.novf * 64] = stk[((L.top + 1u) & slot_mask) * 64]; L.novf++; }
+            else atomicOr((unsigned int *)S.err, (unsigned int)PT_LIMIT_F32_STACK);
+        } else {
+            L.cs++;
+        }
+        stk[L.top * 64] = make_uint2(node, __float_as_uint(ext));
+        L.top = (L.top + 1u) & slot_mask;
+    }
+}
+
+// One level of the descent: a segment [ent, ext] of the ray against the plane `s` on axis `a` (a == 3: no plane, a leaf).
+// first: 0 / 1 = the left / right side is visited first; both: the other side follows from `tmid` on.
+__device__ __forceinline__ void plane_q(const LaneStateQ &L, uint32_t a, float s, float ent, float ext, uint32_t &first, bool &both, float &tmid) {
+    const float oa = sel3(a, L.ox, L.oy, L.oz), ia = sel3(a, L.ix, L.iy, L.iz);
+    tmid = (s - oa) * ia;
+    const uint32_t nr = oa > s ? 1u : 0u;
+    const bool leaf = a == 3u;
+    const bool near_only = leaf | !(tmid <= ext) | (tmid < 0.0f);
+    const bool far_only = !near_only & (tmid < ent);
+    both = !near_only & !far_only;
+    first = leaf ? 0u : (far_only ? nr ^ 1u : nr);
+}
+
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool lane_turn(LaneStateQ &L, const DevScene &S, uint2 *stk, uint32_t slot_mask, uint32_t *work, bool active = true) {
+    bool done = false;
+    const bool at_leaf = L.nlink == 0xFFFFFFFFu;
+    if (active & at_leaf & (L.n0 < L.n1)) {
+        const float4 *tp = (const float4 *)((const char *)S.refTriF + L.n0);
+        const float4 A = tp[0], B = tp[1], C = tp[2];
+        L.n0 += 48u;
+        const f32x2 ex = {B.x, B.y}, ey = {B.z, B.w}, ez = {C.x, C.y};
+        L.dtx.y = L.ox - A.x; L.dty.y = L.oy - A.y; L.dtz.y = L.oz - A.z;
+        const f32x2 dtx = L.dtx, dty = L.dty, dtz = L.dtz;
+        const f32x2 pqx = dty * ez - dtz * ey, pqy = dtz * ex - dtx * ez, pqz = dtx * ey - dty * ex;
+        const f32x2 dn = pqx * ex.yx + pqy * ey.yx + pqz * ez.yx;
+        const f32x2 uvn = pqx * dtx.yx + pqy * dty.yx + pqz * dtz.yx;
+        const float inv = __builtin_amdgcn_rcpf(dn.x);
+        const float u = uvn.x * inv, v = uvn.y * inv, t = dn.y * inv;
+        int id = __float_as_int(A.w);
+        bool hit = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f) & (t < L.tmin) & (id != L.skip);
+        L.tmin = hit ? t : L.tmin; L.hu = hit ? u : L.hu; L.hv = hit ? v : L.hv; L.htri = hit ? id : L.htri;
+        if (ANY) done = hit;
+    }
+    if (active & !(at_leaf & (L.n0 < L.n1)) & !done) {
+        uint32_t curr;
+        if (!at_leaf) {
+            // ---- two levels down: up to four grandchildren in front-to-back order; the first is taken, the others pushed ----
+            const uint32_t link = L.nlink, base = link & ~63u;
+            const float s0 = __uint_as_float(L.n0), s1 = __uint_as_float(L.n1), s2 = __uint_as_float(L.n2);
+            uint32_t h1; bool both0; float t0;
+            plane_q(L, link & 3u, s0, L.ent, L.ext, h1, both0, t0);
+            const float e1 = both0 ? t0 : L.ext;                       // end of the first half's segment
+            const bool second = both0 & (t0 < L.tmin);                 // the other half is visited afterwards
+            uint32_t ga, gb; bool botha, bothb; float ta, tb;
+            plane_q(L, (link >> (h1 ? 4 : 2)) & 3u, h1 ? s2 : s1, L.ent, e1, ga, botha, ta);
+            plane_q(L, (link >> (h1 ? 2 : 4)) & 3u, h1 ? s1 : s2, t0, L.ext, gb, bothb, tb);
+            const uint32_t slot_a = base + (h1 * 2u + ga) * 16u, slot_b = base + ((h1 ^ 1u) * 2u + gb) * 16u;
+            // pushes, farthest first
+            push_q(L, S, stk, slot_mask, second & bothb & (tb < L.tmin), slot_b ^ 16u, L.ext);
+            push_q(L, S, stk, slot_mask, second, slot_b, bothb ? tb : L.ext);
+            push_q(L, S, stk, slot_mask, botha & (ta < L.tmin), slot_a ^ 16u, e1);
+            curr = slot_a;
+            L.ext = botha ? ta : e1;
+            L.cs += 256u;
+        } else {
+            // ---- leaf done: the next segment starts where this one ended ----
+            const uint32_t cnt = L.cs & 0xFFu;
+            const bool finished = L.ext >= L.tmin;
+            const bool pop_ring = !finished & (cnt != 0);
+            const bool pop_ovf = !finished & (cnt == 0) & (L.novf != 0);
+            const bool exhausted = !finished & (cnt == 0) & (L.novf == 0);
+            const uint32_t ptop = (L.top - 1u) & slot_mask;
+            uint2 e = stk[ptop * 64];
+            if (pop_ovf) { L.novf--; e = overflow_column(S)[(size_t)L.novf * 64]; }
+            curr = (pop_ring | pop_ovf) ? e.x : 0u;
+            L.ent = L.ext;
+            L.ext = (pop_ring | pop_ovf) ? __uint_as_float(e.y) : L.ext;
+            L.top = pop_ring ? ptop : L.top;
+            L.cs += 256u - (uint32_t)pop_ring;
+            done = finished | exhausted;
+        }
+        const bool runaway = L.cs > ((uint32_t)FS_MAX_STEPS << 8);
+        if (runaway) atomicOr((unsigned int *)S.err, (unsigned int)PT_LIMIT_F32_STEPS);
+        done = done | runaway;
+        load_quad(L, S, curr);
+        if (COUNT && !done) { work[0]++; work[1] += tris_here(L); }
+    }
+    return done;
+}

@@ -28,6 +28,6 @@ import json, bench
 j = json.load(open('$OUT/bench_under_trace.json'))
 print('# kernel_source_hash', bench.kernel_source_hash())
 print('# rays_per_launch', j['roofline']['rays_per_launch'])")
-{ echo "$HDR"; python3 tools/pmc_summary.py "$OUT" "k_trace_closest<false>"; } > "$OUT/pmc_k_trace_closest.txt"
+{ echo "$HDR"; python3 tools/pmc_summary.py "$OUT" "k_trace_closest<false"; } > "$OUT/pmc_k_trace_closest.txt"
 { echo "$HDR"; python3 tools/pmc_summary.py "$OUT" "k_primary_exact"; } > "$OUT/pmc_k_primary_exact.txt"
 ls "$OUT/trace"

@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-want = sys.argv[2] if len(sys.argv) > 2 else "k_trace_closest<false>"
+want = sys.argv[2] if len(sys.argv) > 2 else "k_trace_closest<false"
 agg = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
     for row in csv.DictReader(open(f)):

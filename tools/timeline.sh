@@ -16,7 +16,7 @@ rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].sp
 rows.sort()
 j = json.load(open(os.path.join(out, "bench.json")))
 # the timed region: the last steps * launches_per_step closest-hit launches of the <false> instantiation, and what runs between them
-tr = [r for r in rows if "k_trace_closest<false>" in r[2]]
+tr = [r for r in rows if "k_trace_closest<false" in r[2]]
 per_step = len(tr) // (j["steps"] + j["warmup"])
 first = tr[j["warmup"] * per_step]
 prim = [r for r in rows if "k_primary_exact" in r[2] and r[0] <= first[0]]
@@ -44,7 +44,7 @@ print(f"timed region {span:.2f} ms over {j['steps']} steps = {span / j['steps']:
 print(f"device idle (no kernel running) {span - covered / 1e6:.2f} ms = {100 * (1 - covered / 1e6 / span):.1f} %")
 for n, b in sorted(busy.items(), key=lambda x: -x[1]):
     print(f"  {n:42s} {b:9.2f} ms  {100 * b / span:5.1f} % of the region")
-tt = busy.get("void k_trace_closest<false>", 0)
+tt = sum(b for n, b in busy.items() if "k_trace_closest<false" in n)
 print(f"not covered by the closest-hit kernel: {span - tt:.2f} ms = {100 * (1 - tt / span):.1f} %")
 PY
 rm -rf "$OUT/trace"
