@@ -1,5 +1,7 @@
 // fp32 kd traversal as a per-lane state machine (the persistent-wave loop that
-// drives it is in pt_persistent.h).
+// drives it is in pt_persistent.h).  This file walks binary node records; pt_trace_quad.h
+// is the same machine over quad records (two levels per record), which the kernels use
+// whenever the tree has them.
 //
 // Why this shape.  Rays differ a lot in length (a ray that threads a cluster of
 // fat nodes costs tens of times the mean), and the lanes of a wave are in
