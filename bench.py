@@ -47,7 +47,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, spec
 
 
-KERNEL_SOURCES = ("pt_fast.hip", "pt_trace_f32.h", "pt_persistent.h", "pt_refine.hip", "pt_scene_dev.h")
+KERNEL_SOURCES = ("pt_fast.hip", "pt_trace_f32.h", "pt_trace_quad.h", "pt_persistent.h", "pt_refine.hip", "pt_scene_dev.h")
 
 
 def kernel_source_hash():
@@ -126,7 +126,10 @@ def physical_roofline(workload, n_node, n_tri, kernel_mrays, ms_launch, rays_lau
         if "TA_BUSY_avr" in v and "GRBM_GUI_ACTIVE" in v:
             phys["ta_busy"] = round(v["TA_BUSY_avr"] / (v["GRBM_GUI_ACTIVE"] / 8.0), 3)
         if "SQ_INSTS_VALU" in v and "GRBM_GUI_ACTIVE" in v:
-            phys["valu_issue"] = round(v["SQ_INSTS_VALU"] * 4.0 / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 3)
+            # instructions x 4 cycles (a wave64 instruction on a 16-lane SIMD) over the SIMD cycles of the launch; the raw figure
+            # can pass 1 by a percent (an instruction whose upper or lower 32 lanes are all idle takes fewer cycles)
+            raw = v["SQ_INSTS_VALU"] * 4.0 / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+            phys["valu_issue"], phys["valu_issue_raw"] = round(min(raw, 1.0), 3), round(raw, 3)
         tr = pmc_traffic(workload, rays_launch)
         if tr and ms_launch > 0:
             phys["hbm_side_gb_per_s"] = round(tr[0] / (ms_launch * 1e-3), 1)
@@ -142,6 +145,8 @@ def physical_roofline(workload, n_node, n_tri, kernel_mrays, ms_launch, rays_lau
     units = {k: phys[k] for k in ("ta_busy", "valu_issue") if k in phys}
     if units:
         top = max(units, key=units.get)
+        phys["limiter"] = ("per-lane load requests through the L1 address path (TA), then VALU issue" if top == "ta_busy" else
+                           "VALU issue, then per-lane load requests through the L1 address path (TA)")
         phys["frac"] = units[top]
         phys["frac_of"] = {"ta_busy": "L1 address path (TA) busy cycles / cycles", "valu_issue": "VALU issue cycles / SIMD cycles"}[top]
     return phys
