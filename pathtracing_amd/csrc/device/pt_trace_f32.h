@@ -67,14 +67,32 @@ __device__ __forceinline__ uint32_t tris_here(const LaneState &L) { return (L.te
 
 __device__ __forceinline__ float sel3(uint32_t a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
 
-__device__ __forceinline__ void load_node(LaneState &L, const DevScene &S, uint32_t off) {
-    const uint4 n = *(const uint4 *)((const char *)S.nodeF + off);
-    L.nsplit = __uint_as_float(n.x); L.nlink = n.y; L.toff = n.z; L.tend = n.w;
+// One Moeller-Trumbore test (two-sided) of the 48-byte triangle record at byte offset `toff` against the lane's ray;
+// updates the lane's best hit and returns whether this triangle became it.  LS: LaneState or LaneStateQ (same ray fields).
+// Both cross products and all four dot products run as packed fp32 pairs (v_pk_mul_f32 / v_pk_fma_f32): lane .x of a
+// pair works on P = d x e2, lane .y on Q = T x e1.
+template <class LS>
+__device__ __forceinline__ bool triangle_unit(LS &L, const DevScene &S, uint32_t toff) {
+    const float4 *tp = (const float4 *)((const char *)S.refTriF + toff);
+    const float4 A = tp[0], B = tp[1], C = tp[2];
+    const f32x2 ex = {B.x, B.y}, ey = {B.z, B.w}, ez = {C.x, C.y};                 // (e2, e1) per axis
+    L.dtx.y = L.ox - A.x; L.dty.y = L.oy - A.y; L.dtz.y = L.oz - A.z;              // (d, T = o - v0)
+    const f32x2 dtx = L.dtx, dty = L.dty, dtz = L.dtz;
+    const f32x2 pqx = dty * ez - dtz * ey, pqy = dtz * ex - dtx * ez, pqz = dtx * ey - dty * ex;   // (P, Q)
+    const f32x2 dn = pqx * ex.yx + pqy * ey.yx + pqz * ez.yx;                      // (det = P . e1, Q . e2)
+    const f32x2 uvn = pqx * dtx.yx + pqy * dty.yx + pqz * dtz.yx;                  // (P . T, Q . d)
+    const float inv = __builtin_amdgcn_rcpf(dn.x);
+    const float u = uvn.x * inv, v = uvn.y * inv, t = dn.y * inv;
+    const int id = __float_as_int(A.w);
+    // every comparison is false for a NaN, so a degenerate triangle never hits
+    const bool hit = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f) & (t < L.tmin) & (id != L.skip);
+    L.tmin = hit ? t : L.tmin; L.hu = hit ? u : L.hu; L.hv = hit ? v : L.hv; L.htri = hit ? id : L.htri;
+    return hit;
 }
 
-// Start a ray; false when it misses the scene's box (nothing to traverse).
-__device__ __forceinline__ bool lane_begin(LaneState &L, const DevScene &S, const RootBox &b, float ox, float oy, float oz,
-                                           float dx, float dy, float dz, float tmax, int skip) {
+// The ray into the lane state and its segment inside the scene's box; false when it misses the box.
+template <class LS>
+__device__ __forceinline__ bool ray_unit(LS &L, const RootBox &b, float ox, float oy, float oz, float dx, float dy, float dz, float tmax, int skip) {
     L.ox = ox; L.oy = oy; L.oz = oz; L.dtx.x = dx; L.dty.x = dy; L.dtz.x = dz;
     L.ix = __builtin_amdgcn_rcpf(dx); L.iy = __builtin_amdgcn_rcpf(dy); L.iz = __builtin_amdgcn_rcpf(dz);
     float a0 = (b.lx - ox) * L.ix, a1 = (b.hx - ox) * L.ix;
@@ -84,7 +102,18 @@ __device__ __forceinline__ bool lane_begin(LaneState &L, const DevScene &S, cons
     L.ext = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tmax));
     L.tmin = tmax; L.htri = -1; L.hu = 0; L.hv = 0; L.skip = skip;
     L.top = 0; L.cs = 0; L.novf = 0;
-    if (!(L.ent <= L.ext)) return false;
+    return L.ent <= L.ext;
+}
+
+__device__ __forceinline__ void load_node(LaneState &L, const DevScene &S, uint32_t off) {
+    const uint4 n = *(const uint4 *)((const char *)S.nodeF + off);
+    L.nsplit = __uint_as_float(n.x); L.nlink = n.y; L.toff = n.z; L.tend = n.w;
+}
+
+// Start a ray; false when it misses the scene's box (nothing to traverse).
+__device__ __forceinline__ bool lane_begin(LaneState &L, const DevScene &S, const RootBox &b, float ox, float oy, float oz,
+                                           float dx, float dy, float dz, float tmax, int skip) {
+    if (!ray_unit(L, b, ox, oy, oz, dx, dy, dz, tmax, skip)) return false;
     load_node(L, S, 0);
     return true;
 }
@@ -103,24 +132,9 @@ template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool lane_turn(LaneState &L, const DevScene &S, uint2 *stk, uint32_t slot_mask, uint32_t *work, bool active = true) {
     bool done = false;
     if (active & (L.toff < L.tend)) {
-        // ---- one triangle of the current node (Moeller-Trumbore, two-sided) ----
-        const float4 *tp = (const float4 *)((const char *)S.refTriF + L.toff);
-        const float4 A = tp[0], B = tp[1], C = tp[2];
+        // ---- one triangle of the current node ----
+        const bool hit = triangle_unit(L, S, L.toff);
         L.toff += 48u;
-        // Both cross products and all four dot products of the test run as packed fp32 pairs
-        // (v_pk_mul_f32 / v_pk_fma_f32): lane .x of a pair works on P = d x e2, lane .y on Q = T x e1.
-        const f32x2 ex = {B.x, B.y}, ey = {B.z, B.w}, ez = {C.x, C.y};                 // (e2, e1) per axis
-        L.dtx.y = L.ox - A.x; L.dty.y = L.oy - A.y; L.dtz.y = L.oz - A.z;              // (d, T = o - v0)
-        const f32x2 dtx = L.dtx, dty = L.dty, dtz = L.dtz;
-        const f32x2 pqx = dty * ez - dtz * ey, pqy = dtz * ex - dtx * ez, pqz = dtx * ey - dty * ex;   // (P, Q)
-        const f32x2 dn = pqx * ex.yx + pqy * ey.yx + pqz * ez.yx;                      // (det = P . e1, Q . e2)
-        const f32x2 uvn = pqx * dtx.yx + pqy * dty.yx + pqz * dtz.yx;                  // (P . T, Q . d)
-        const float inv = __builtin_amdgcn_rcpf(dn.x);
-        const float u = uvn.x * inv, v = uvn.y * inv, t = dn.y * inv;
-        int id = __float_as_int(A.w);
-        // every comparison is false for a NaN, so a degenerate triangle never hits
-        bool hit = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f) & (t < L.tmin) & (id != L.skip);
-        L.tmin = hit ? t : L.tmin; L.hu = hit ? u : L.hu; L.hv = hit ? v : L.hv; L.htri = hit ? id : L.htri;
         if (ANY) done = hit;
     }
     if (active & !(L.toff < L.tend) & !done) {

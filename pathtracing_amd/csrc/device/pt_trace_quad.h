@@ -27,16 +27,7 @@ __device__ __forceinline__ void load_quad(LaneStateQ &L, const DevScene &S, uint
 
 __device__ __forceinline__ bool lane_begin(LaneStateQ &L, const DevScene &S, const RootBox &b, float ox, float oy, float oz,
                                              float dx, float dy, float dz, float tmax, int skip) {
-    L.ox = ox; L.oy = oy; L.oz = oz; L.dtx.x = dx; L.dty.x = dy; L.dtz.x = dz;
-    L.ix = __builtin_amdgcn_rcpf(dx); L.iy = __builtin_amdgcn_rcpf(dy); L.iz = __builtin_amdgcn_rcpf(dz);
-    float a0 = (b.lx - ox) * L.ix, a1 = (b.hx - ox) * L.ix;
-    float b0 = (b.ly - oy) * L.iy, b1 = (b.hy - oy) * L.iy;
-    float c0 = (b.lz - oz) * L.iz, c1 = (b.hz - oz) * L.iz;
-    L.ent = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-    L.ext = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tmax));
-    L.tmin = tmax; L.htri = -1; L.hu = 0; L.hv = 0; L.skip = skip;
-    L.top = 0; L.cs = 0; L.novf = 0;
-    if (!(L.ent <= L.ext)) return false;
+    if (!ray_unit(L, b, ox, oy, oz, dx, dy, dz, tmax, skip)) return false;
     load_quad(L, S, 0);
     return true;
 }
@@ -77,20 +68,8 @@ __device__ __forceinline__ bool lane_turn(LaneStateQ &L, const DevScene &S, uint
     bool done = false;
     const bool at_leaf = L.nlink == 0xFFFFFFFFu;
     if (active & at_leaf & (L.n0 < L.n1)) {
-        const float4 *tp = (const float4 *)((const char *)S.refTriF + L.n0);
-        const float4 A = tp[0], B = tp[1], C = tp[2];
+        const bool hit = triangle_unit(L, S, L.n0);
         L.n0 += 48u;
-        const f32x2 ex = {B.x, B.y}, ey = {B.z, B.w}, ez = {C.x, C.y};
-        L.dtx.y = L.ox - A.x; L.dty.y = L.oy - A.y; L.dtz.y = L.oz - A.z;
-        const f32x2 dtx = L.dtx, dty = L.dty, dtz = L.dtz;
-        const f32x2 pqx = dty * ez - dtz * ey, pqy = dtz * ex - dtx * ez, pqz = dtx * ey - dty * ex;
-        const f32x2 dn = pqx * ex.yx + pqy * ey.yx + pqz * ez.yx;
-        const f32x2 uvn = pqx * dtx.yx + pqy * dty.yx + pqz * dtz.yx;
-        const float inv = __builtin_amdgcn_rcpf(dn.x);
-        const float u = uvn.x * inv, v = uvn.y * inv, t = dn.y * inv;
-        int id = __float_as_int(A.w);
-        bool hit = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f) & (t < L.tmin) & (id != L.skip);
-        L.tmin = hit ? t : L.tmin; L.hu = hit ? u : L.hu; L.hv = hit ? v : L.hv; L.htri = hit ? id : L.htri;
         if (ANY) done = hit;
     }
     if (active & !(at_leaf & (L.n0 < L.n1)) & !done) {
