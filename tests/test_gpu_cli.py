@@ -133,6 +133,26 @@ def test_rm_job_frames_do_not_depend_on_the_number_of_ranks(tmp_path, cbox):
         assert np.array_equal(a, want), v
 
 
+@pytest.mark.parametrize("scene,model", [("car", "omp"), ("cbox", "main")])
+def test_kernel_variants_write_the_same_frame(tmp_path, scene, model):
+    """The fp32 GI path has two forms of its tree walk (quad records, two levels per record, and the binary records kept
+    for the no-allocation entry point) and, for the mainOMP model, shading and summing as one kernel or as two.  They are
+    the same computation: a -gi frame is the same bytes whichever is chosen (the switches are read once per process,
+    hence one process per variant)."""
+    frames = {}
+    for name, env in (("default", {}), ("binary records", {"PT_TUNE_QUAD": "0"}), ("two kernels", {"PT_TUNE_FUSED_SUM": "0"}),
+                      ("both", {"PT_TUNE_QUAD": "0", "PT_TUNE_FUSED_SUM": "0"})):
+        out = tmp_path / name.replace(" ", "_")
+        os.makedirs(out)
+        r = subprocess.run([PTMAIN, scene, "-gi", "--model", model, "--spp", "70", "--size", "96", "--out", str(out)], cwd=ROOT,
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        frames[name] = read_ppm(out / f"{scene}.ppm")
+    assert int(frames["default"].max()) > 0
+    for name, f in frames.items():
+        assert np.array_equal(f, frames["default"]), name
+
+
 def test_bench_with_two_ranks_started_by_itself(cbox):
     """`python bench.py --gpus 2` without a launcher around it (how the round driver starts it) runs two ranks -- here the
     gloo rehearsal, both on this one GPU -- and rank 0 prints one line for the whole job; the one-rank line has the
