@@ -204,13 +204,18 @@ def free_port():
 def launch_ranks(n):
     """`python bench.py --gpus N` started as one plain process: start the N ranks (one per GPU) as a
     torch.distributed.run child process -- a child, not an exec, and before this process has touched a GPU or
-    imported torch -- pass its output through (rank 0 prints the JSON line) and return its exit code."""
+    imported torch -- pass rank 0's JSON line through on stdout (whatever else the ranks or their libraries write to
+    stdout goes to stderr, so that stdout holds the one line) and return its exit code."""
     import subprocess
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, errors="replace")
+    for line in child.stdout:
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        (sys.stdout if line.startswith("{") else sys.stderr).flush()
+    return child.wait()
 
 
 def main():
