@@ -68,16 +68,19 @@ __device__ __forceinline__ bool tile_pixel_f(int linear, int size, int &i, int &
     return i < size && j < size;
 }
 
-// createCoordSystem + sample direction, util/lighting.cpp:42-59 and main.cpp:94-96,
-// in fp64 so that the fast path shoots the same sample directions as the fp64 path.
-__device__ __forceinline__ D3 gi_direction(D3 nrm, uint32_t seed, uint32_t view, uint32_t pixel, uint32_t sample, double &r1) {
+// createCoordSystem (util/lighting.cpp:42-48) and the sample direction in that frame (util/lighting.cpp:53-59,
+// main.cpp:94-96), in fp64 so that the fast path shoots the same sample directions as the fp64 path.  The frame
+// belongs to the pixel: it is made once per thread, not once per sample.
+__device__ __forceinline__ void gi_frame(D3 nrm, D3 &Nt, D3 &Nb) {
 #pragma clang fp contract(off)
-    D3 Nt, Nb;
     if (fabs(nrm.x) > fabs(nrm.y))
         Nt = ddivs(d3(nrm.z, 0, -nrm.x), sqrt(nrm.x * nrm.x + nrm.z * nrm.z));
     else
         Nt = ddivs(d3(0, -nrm.z, nrm.y), sqrt(nrm.y * nrm.y + nrm.z * nrm.z));
     Nb = dcross(nrm, Nt);
+}
+__device__ __forceinline__ D3 gi_direction(D3 nrm, D3 Nt, D3 Nb, uint32_t seed, uint32_t view, uint32_t pixel, uint32_t sample, double &r1) {
+#pragma clang fp contract(off)
     D3 sm = sample_hemisphere(seed, view, pixel, sample, r1);
     return d3(sm.x * Nb.x + sm.y * nrm.x + sm.z * Nt.x,
               sm.x * Nb.y + sm.y * nrm.y + sm.z * Nt.y,
@@ -172,11 +175,11 @@ __device__ __forceinline__ uint32_t dir_bin(float x, float y, float z) {
     }
     const float n = (float)(1 << PT_GEN_CELL_BITS), hi = n - 1.0f;
     const uint32_t qu = (uint32_t)fminf(fmaxf((u * 0.5f + 0.5f) * n, 0.0f), hi), qv = (uint32_t)fminf(fmaxf((v * 0.5f + 0.5f) * n, 0.0f), hi);
-    uint32_t m = 0;
-#pragma unroll
-    for (int b = 0; b < PT_GEN_CELL_BITS; b++) m |= (((qu >> b) & 1u) << (2 * b + 1)) | (((qv >> b) & 1u) << (2 * b));
-    return m;
+    // interleave the bits of the two cell coordinates (at most 8 bits each)
+    auto spread = [](uint32_t x) { x = (x | (x << 4)) & 0x0F0Fu; x = (x | (x << 2)) & 0x3333u; return (x | (x << 1)) & 0x5555u; };
+    return (spread(qu) << 1) | spread(qv);
 }
+static_assert(PT_GEN_CELL_BITS <= 8, "the bit interleave of dir_bin handles 8 bits per coordinate");
 
 __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, FrameBuffers F, FastBuffers Q, int s0, int nb, int groups) {
     __shared__ uint32_t hist[PT_GEN_BINS];
@@ -210,6 +213,8 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
             }
         }
     }
+    D3 Nt = d3(0, 0, 0), Nb = d3(0, 0, 0);
+    if (pix_valid) gi_frame(nrm, Nt, Nb);
     float4 rd[4];
     float st[4], su[4], sv[4];          // origin-triangle hit of the sample, when there is one
     uint32_t key[4], rank[4];
@@ -220,7 +225,7 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
         if (live && sl < nb) {
             if (pix_valid) {
                 double r1;
-                D3 w = gi_direction(nrm, V.seed, V.view, (uint32_t)p, (uint32_t)(s0 + sl), r1);
+                D3 w = gi_direction(nrm, Nt, Nb, V.seed, V.view, (uint32_t)p, (uint32_t)(s0 + sl), r1);
                 rd[r] = make_float4((float)w.x, (float)w.y, (float)w.z, (float)r1);
                 key[r] = dir_bin(rd[r].x, rd[r].y, rd[r].z);
                 // a ray that hits the triangle it starts on is resolved here; the sign of r1 (>= 0) tells
