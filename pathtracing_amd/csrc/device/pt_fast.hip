@@ -407,11 +407,11 @@ __device__ __forceinline__ void light_f(const float4 *lights, int k, float hx, f
 }
 
 // r1 * castRay(sample ray, depth -1) of the mainOMP model (mainOMP.cpp:55-62,74-75: every light counts as visible;
-// txt * albedo * direct / pi) for queue entry r with hit record h; 0 on a miss.
-__device__ __forceinline__ float4 omp_contribution(const DevScene &S, const FastBuffers &Q, uint32_t r, float4 h) {
+// txt * albedo * direct / pi) for a ray from o along d (d.w: its weight r1) with hit record h; 0 on a miss.
+__device__ __forceinline__ float4 omp_contribution(const DevScene &S, float ox, float oy, float oz, float4 d, float4 h) {
     const int tri = __float_as_int(h.w);
     if (tri < 0) return make_float4(0.f, 0.f, 0.f, 0.f);           // castRay returns 0 on a miss at depth -1
-    const float4 o = Q.rays_o[r], d = Q.rays_d[r];
+    const float3 o = make_float3(ox, oy, oz);
     float ar, ag, ab;
     const SurfF sf = surface_f(S, tri, h.y, h.z, ar, ag, ab);
     ar *= sf.tr; ag *= sf.tg; ab *= sf.tb;
@@ -434,7 +434,8 @@ __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBu
     bool hit = false;
     float4 sp_pos, sp_nrm, sp_base;
     if (in_range && MODEL == PT_MODEL_OMP) {
-        Q.contrib[r] = omp_contribution(S, Q, r, Q.hits[r]);
+        const float4 o = Q.rays_o[r];
+        Q.contrib[r] = omp_contribution(S, o.x, o.y, o.z, Q.rays_d[r], Q.hits[r]);
     } else if (in_range) {
         float4 h = Q.hits[r];
         int tri = __float_as_int(h.w);
@@ -588,6 +589,7 @@ __global__ void __launch_bounds__(PT_SUM_THREADS) k_gi_sum(FrameBuffers F, FastB
 #define PT_FUSED_THREADS 1024
 __global__ void __launch_bounds__(PT_FUSED_THREADS) k_shade_sum_omp(DevScene S, FrameBuffers F, FastBuffers Q, int size, int nb, int first_batch) {
     __shared__ float cr[64 * 64], cg[64 * 64], cb[64 * 64];
+    __shared__ float org[3][64];                    // the rays' origins: the primary hits of the tile's pixels, as k_gi_gen rounds them
     const int tid = threadIdx.x, qtile = blockIdx.x;
     if (qtile == 0 && tid == 0) {
         Q.totals[0] += Q.counts[0];
@@ -600,14 +602,20 @@ __global__ void __launch_bounds__(PT_FUSED_THREADS) k_shade_sum_omp(DevScene S, 
     const size_t p = mine ? (size_t)i * size + j : 0;
     double ax = 0, ay = 0, az = 0;
     if (mine && !first_batch) { ax = F.gi_acc[3 * p]; ay = F.gi_acc[3 * p + 1]; az = F.gi_acc[3 * p + 2]; }
-    const bool shot = mine && !(F.ghit[3 * p] == -99999);
+    bool shot = false;
+    if (mine) {
+        const double hx = F.ghit[3 * p], hy = F.ghit[3 * p + 1], hz = F.ghit[3 * p + 2];
+        shot = !(hx == -99999);
+        org[0][tid] = (float)hx; org[1][tid] = (float)hy; org[2][tid] = (float)hz;
+    }
+    __syncthreads();
     for (int g0 = 0; g0 < nb && valid; g0 += 64) {
         const int gs = nb - g0 < 64 ? nb - g0 : 64;
         const uint32_t base = t0 * (uint32_t)nb + valid * (uint32_t)g0, n = valid * (uint32_t)gs;
         for (uint32_t k = tid; k < n; k += PT_FUSED_THREADS) {
             const uint32_t r = base + k;
-            const float4 c = omp_contribution(S, Q, r, Q.hits[r]);
-            const uint32_t at = Q.ray_slot[r] - (uint32_t)g0 * 64u;
+            const uint32_t code = Q.ray_slot[r], px = code & 63u, at = code - (uint32_t)g0 * 64u;
+            const float4 c = omp_contribution(S, org[0][px], org[1][px], org[2][px], Q.rays_d[r], Q.hits[r]);
             cr[at] = c.x; cg[at] = c.y; cb[at] = c.z;
         }
         __syncthreads();

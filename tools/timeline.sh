@@ -46,5 +46,13 @@ for n, b in sorted(busy.items(), key=lambda x: -x[1]):
     print(f"  {n:42s} {b:9.2f} ms  {100 * b / span:5.1f} % of the region")
 tt = sum(b for n, b in busy.items() if "k_trace_closest<false" in n)
 print(f"not covered by the closest-hit kernel: {span - tt:.2f} ms = {100 * (1 - tt / span):.1f} %")
+# the kernels of the last timed step in start order (ms from the step's first kernel)
+steps_prim = [r for r in rows if "k_primary_exact" in r[2] and t0 <= r[0] <= t1]
+if steps_prim:
+    b = steps_prim[-1][0]
+    print("last step, kernel by kernel (start .. end, ms):")
+    for s_, e_, n in sel:
+        if s_ >= b and e_ - s_ > 20000:
+            print(f"  {(s_ - b) / 1e6:8.3f} .. {(e_ - b) / 1e6:8.3f}  {n}")
 PY
 rm -rf "$OUT/trace"
