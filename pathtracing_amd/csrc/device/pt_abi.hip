@@ -59,6 +59,7 @@ float bits_to_float(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
 
 struct Workspace {
     int size = 0, batch = 0, nsub = 0;
+    bool shadow = false;              // the shadow-ray queue of the main.cpp model's fp32 GI path is allocated
     FrameBuffers F{};
     FastBuffers Q[2] = {};
     SubBuffers B{};
@@ -476,14 +477,18 @@ int check_limits(PtScene *sc, const char *what) {
     return fail(PT_ERR_LIMIT, limit_message(what, e));
 }
 
-int ensure_workspace(PtScene *sc, int size, int batch, bool fast, int nsub) {
+int ensure_workspace(PtScene *sc, int size, int batch, bool fast, int nsub, bool shadow) {
     Workspace &ws = sc->ws;
     bool have_fast = ws.Q[0].rays_o != nullptr;
-    if (ws.size == size && ws.batch >= batch && (!fast || have_fast) && ws.nsub >= nsub) return PT_OK;
+    shadow = shadow && fast;
+    if (shadow && sc->S.n_light > 32)
+        return fail(PT_ERR_LIMIT, "the fp32 GI path of the main.cpp model handles at most 32 lights (use gi_precision = exact)");
+    if (ws.size == size && ws.batch >= batch && (!fast || have_fast) && ws.nsub >= nsub && (!shadow || ws.shadow)) return PT_OK;
     if (ws.size == size) {
         if (batch < ws.batch) batch = ws.batch;
         if (nsub < ws.nsub) nsub = ws.nsub;
         fast = fast || have_fast;
+        shadow = shadow || ws.shadow;
     }
     ws_release(ws);
     size_t P = (size_t)size * size;
@@ -510,9 +515,9 @@ int ensure_workspace(PtScene *sc, int size, int batch, bool fast, int nsub) {
     WS(ws_alloc(ws, P * nsub * 3, &ws.B.tuv));
     WS(ws_alloc(ws, P * nsub, &ws.B.mirror));
     WS(ws_alloc(ws, P * nsub * 3, &ws.B.mdir));
-    if (fast) WS(fast_alloc(ws.Q, P, batch, ws_alloc_cb, &ws));
+    if (fast) WS(fast_alloc(ws.Q, P, batch, shadow ? sc->S.n_light : 0, ws_alloc_cb, &ws));
 #undef WS
-    ws.size = size; ws.batch = batch; ws.nsub = nsub;
+    ws.size = size; ws.batch = batch; ws.nsub = nsub; ws.shadow = shadow;
     return PT_OK;
 }
 
@@ -552,7 +557,7 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
         if (batch < 1) batch = 1;
         if (batch > N) batch = N;
     }
-    rc = ensure_workspace(sc, size, batch, fast, o->rb ? 9 : 1);
+    rc = ensure_workspace(sc, size, batch, fast, o->rb ? 9 : 1, o->model == PT_MODEL_MAIN);
     if (rc) return rc;
     FrameBuffers &F = sc->ws.F;
     ViewParams V{};

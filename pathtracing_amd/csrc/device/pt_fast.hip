@@ -7,8 +7,10 @@
 //   k_trace_closest kd traversal, nearest hit: persistent waves, a triangle test and/or a
 //                   node step per lane per turn, per-lane ring stack in LDS (pt_trace_f32.h)
 //   k_shade_gi      surface properties + lights; OMP model: writes the sample's
-//                   contribution; MAIN model: compacts hits into a shading-point queue
-//   k_shadow_gi     MAIN model: any-hit traversal towards every light (same machinery)
+//                   contribution; MAIN model: compacts hits into a shading-point queue and
+//                   queues a shadow ray per light that can reach the point
+//   k_shadow_gi     MAIN model: any-hit query per shadow ray (same machinery)
+//   k_light_sum     MAIN model: the lights of a point added in order, each if its ray found nothing
 //   k_gi_sum        ordered per-pixel sum of the pass's contributions (fp64)
 //   k_shade_sum_omp mainOMP model: the two stages before in one kernel (the contributions stay in LDS)
 //
@@ -56,6 +58,26 @@ __device__ __forceinline__ uint32_t block_append(bool valid, uint32_t *counter) 
     }
     __syncthreads();
     return block_base + wave_n[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+// The same for n entries per thread (n may be 0): the thread's entries are consecutive, threads in order.
+__device__ __forceinline__ uint32_t block_append_n(uint32_t n, uint32_t *counter) {
+    __shared__ uint32_t wave_n[PT_APPEND_BLOCK / 64];
+    __shared__ uint32_t block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t incl = n;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t nbr = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += nbr;
+    }
+    if (lane == 63) wave_n[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < nw; w++) { uint32_t c = wave_n[w]; wave_n[w] = tot; tot += c; }
+        block_base = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    return block_base + wave_n[wave] + incl - n;
 }
 
 // ---- stage 1: ray generation from the G-buffer --------------------------------
@@ -427,6 +449,22 @@ __device__ __forceinline__ float4 omp_contribution(const DevScene &S, float ox, 
     return make_float4(k * ar * dr, k * ag * dg, k * ab * db, 0.f);
 }
 
+// main.cpp:60-66 for light k at a shading point (position xyz | triangle, normal xyz): direction and distance of the
+// shadow ray and cos * radiance of the light; false when no ray is traced because the light adds nothing whatever the
+// ray says -- it is behind the surface, or the triangle the ray starts on shadows it.  The reference starts the ray
+// 1e-4 along the shading normal and tests it against that triangle as well (main.cpp:63-66): the triangle shadows the
+// point when the light is on the other side of its plane than the shading normal.  Decided here by signs; the search
+// skips the triangle.
+__device__ __forceinline__ bool shadow_ray_wanted(const DevScene &S, int k, float4 pos, float4 nrm, float &lx, float &ly, float &lz, float &dis) {
+#pragma clang fp contract(off)
+    float sr, sg, sb;
+    light_f(S.lightsF, k, pos.x, pos.y, pos.z, lx, ly, lz, dis, sr, sg, sb);
+    const float c = lx * nrm.x + ly * nrm.y + lz * nrm.z;
+    if (!(c > 0.0f)) return false;
+    const float4 ng = S.triNgF[__float_as_int(pos.w)];
+    return !((lx * ng.x + ly * ng.y + lz * ng.z) * (nrm.x * ng.x + nrm.y * ng.y + nrm.z * ng.z) < 0.0f);
+}
+
 template <int MODEL>
 __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBuffers Q) {
     uint32_t r = blockIdx.x * PT_APPEND_BLOCK + threadIdx.x;
@@ -463,85 +501,87 @@ __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBu
         }
     }
     if (MODEL == PT_MODEL_MAIN) {
+        // The shadow rays of the point, one per light that can add something (shadow_ray_wanted), are made here, where every
+        // lane has a point, and queued one after the other in light order; the any-hit kernel is then a plain ray query.
+        uint32_t want = 0;                                     // bit k: light k gets a ray
+        float4 one = make_float4(0.f, 0.f, 0.f, 0.f);          // direction and length of the newest ray
+        if (hit)
+            for (int k = 0; k < S.n_light; k++) {
+                float lx, ly, lz, dis;
+                if (shadow_ray_wanted(S, k, sp_pos, sp_nrm, lx, ly, lz, dis)) { want |= 1u << k; one = make_float4(lx, ly, lz, dis); }
+            }
         const uint32_t q = block_append(hit, &Q.counts[1]);
-        if (hit) { Q.sp_pos[q] = sp_pos; Q.sp_nrm[q] = sp_nrm; Q.sp_base[q] = sp_base; }
+        uint32_t sq = block_append_n((uint32_t)__popc(want), &Q.counts[2]);
+        if (hit) {
+            // the point's record: position | lights with a ray, normal | queue index of the GI ray, base colour | first shadow ray
+            Q.sp_pos[q] = make_float4(sp_pos.x, sp_pos.y, sp_pos.z, __uint_as_float(want));
+            Q.sp_nrm[q] = sp_nrm;
+            Q.sp_base[q] = make_float4(sp_base.x, sp_base.y, sp_base.z, __uint_as_float(sq));
+            if (__popc(want) == 1) {                            // the usual case: the one ray is still in registers
+                Q.sh_o[sq] = sp_pos; Q.sh_d[sq] = one;
+            } else {
+                for (int k = 0; k < S.n_light; k++) {
+                    if (!((want >> k) & 1u)) continue;
+                    float lx, ly, lz, dis;
+                    shadow_ray_wanted(S, k, sp_pos, sp_nrm, lx, ly, lz, dis);
+                    Q.sh_o[sq] = sp_pos;
+                    Q.sh_d[sq] = make_float4(lx, ly, lz, dis);
+                    sq++;
+                }
+            }
+        }
     }
 }
 
 // ---- stage 4 (MAIN model): shadow rays of the GI hits ------------------------------
-// One work item = one shading point; its lights are visited in order by the same lane.
+// One work item = one shadow ray; the answer (1.0f: nothing between the point and the light) replaces the ray's length.
 template <class LS>
-struct ShadowPolicy {
+struct AnyHitPolicy {
     const DevScene &S;
     const FastBuffers &Q;
     const RootBox box;
     uint2 *stk;
     uint32_t slot_mask;
     LS L;
-    // Little is kept per lane: the point is the origin of the running ray (L.ox..), its triangle is
-    // L.skip, and the normal / base colour are re-read from the queue when a light is chosen or the
-    // point completes.
-    float pr, pg, pb;           // cos * radiance of the light whose ray is running
-    float dr, dg, db;           // sum over the visible lights so far
-    uint32_t item, shadow;
-    int k;
-    bool fresh;
-    __device__ __forceinline__ bool start(uint32_t it) {
-        item = it;
-        const float4 pos = Q.sp_pos[item];
-        L.ox = pos.x; L.oy = pos.y; L.oz = pos.z; L.skip = __float_as_int(pos.w);
-        dr = dg = db = 0.f; k = 0;
-        fresh = true;               // the first turn only picks the first light (keeps one copy of that code)
-        return true;
+    uint32_t q;
+    __device__ __forceinline__ void answer(bool visible) { ((float *)(Q.sh_d + q))[3] = visible ? 1.0f : 0.0f; }
+    __device__ __forceinline__ bool step(bool active) {
+        const bool done = lane_turn<true, false>(L, S, stk, slot_mask, nullptr, active);
+        if (done) answer(L.htri < 0);
+        return active & !done;
     }
-    // A turn: one unit of the running shadow ray; when it ends (or the point is new), find the
-    // next light in front of the surface and begin its ray, or complete the point when there
-    // is none (a light behind the surface adds 0 whatever its ray says).
-    __device__ __forceinline__ bool step(bool active) { return active ? turn() : false; }
-    __device__ __forceinline__ bool turn() {
-        if (!fresh) {
-            if (!lane_turn<true, false>(L, S, stk, slot_mask, nullptr)) return true;
-            if (L.htri < 0) { dr += pr; dg += pg; db += pb; }
-            k++;
-        }
-        fresh = false;
-        const float4 nrm = Q.sp_nrm[item];
-        const float px = L.ox, py = L.oy, pz = L.oz;
-        const int tri = L.skip;
-        // The shadow ray starts 1e-4 along the shading normal and the reference tests it against the
-        // triangle it starts on as well (main.cpp:63-66): that triangle shadows the point when the light is
-        // on the other side of its plane than the shading normal.  Decided here by signs; the search skips
-        // the triangle.
-        for (; k < S.n_light; k++) {
-            float lx, ly, lz, dis, sr, sg, sb;
-            light_f(S.lightsF, k, px, py, pz, lx, ly, lz, dis, sr, sg, sb);
-            const float c = lx * nrm.x + ly * nrm.y + lz * nrm.z;
-            if (c > 0.0f) {
-                const float4 ng = S.triNgF[tri];
-                const bool self = (lx * ng.x + ly * ng.y + lz * ng.z) * (nrm.x * ng.x + nrm.y * ng.y + nrm.z * ng.z) < 0.0f;
-                if (!self) {
-                    shadow++;                                         // rays traced, not lights considered
-                    pr = c * sr; pg = c * sg; pb = c * sb;
-                    if (lane_begin(L, S, box, px, py, pz, lx, ly, lz, dis, tri)) return true;
-                    dr += pr; dg += pg; db += pb;                     // ray misses the scene box: visible
-                }
-            }
-        }
-        const float4 base = Q.sp_base[item];
-        Q.contrib[__float_as_uint(nrm.w)] = make_float4(base.x * dr, base.y * dg, base.z * db, 0.f);
+    __device__ __forceinline__ bool start(uint32_t item) {
+        q = item;
+        const float4 o = Q.sh_o[q], d = Q.sh_d[q];
+        if (lane_begin(L, S, box, o.x, o.y, o.z, d.x, d.y, d.z, d.w, __float_as_int(o.w))) return true;
+        answer(true);                                              // the ray misses the scene's box
         return false;
     }
 };
 
 template <class LS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) k_shadow_gi(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
+__global__ void __launch_bounds__(64) k_shadow_gi(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
     extern __shared__ uint2 stack[];
-    ShadowPolicy<LS> P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
-    P.shadow = 0; P.fresh = false;
-    persistent_loop(P, Q.counts[1], Q.heads + PT_HEAD_WORDS, chunk, refill_min);
-    uint32_t n = P.shadow;
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&Q.counts[2], n);
+    AnyHitPolicy<LS> P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
+    persistent_loop(P, Q.counts[2], Q.heads + PT_HEAD_WORDS, chunk, refill_min);
+}
+
+// The light loop of a shading point once its shadow rays are answered (main.cpp:60-66,77): the lights in order, each
+// adding cos * radiance when its ray found nothing.
+__global__ void __launch_bounds__(256) k_light_sum(DevScene S, FastBuffers Q) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= Q.counts[1]) return;
+    const float4 pos = Q.sp_pos[p], nrm = Q.sp_nrm[p], base = Q.sp_base[p];
+    uint32_t want = __float_as_uint(pos.w), sq = __float_as_uint(base.w);
+    float dr = 0.f, dg = 0.f, db = 0.f;
+    for (; want; want &= want - 1u, sq++) {
+        if (Q.sh_d[sq].w == 0.0f) continue;                     // something lies between the point and the light
+        float lx, ly, lz, dis, sr, sg, sb;
+        light_f(S.lightsF, __ffs((int)want) - 1, pos.x, pos.y, pos.z, lx, ly, lz, dis, sr, sg, sb);
+        const float c = lx * nrm.x + ly * nrm.y + lz * nrm.z;
+        dr += __fmul_rn(c, sr); dg += __fmul_rn(c, sg); db += __fmul_rn(c, sb);
+    }
+    Q.contrib[__float_as_uint(nrm.w)] = make_float4(base.x * dr, base.y * dg, base.z * db, 0.f);
 }
 
 // ---- stage 5: indirect += r1 * L over the pass's samples, in sample order ------------
@@ -672,9 +712,10 @@ __global__ void __launch_bounds__(64) k_trace_fast_f64io(DevScene S, uint32_t n,
 
 // Two sets of ray arrays, pass counters and queue heads (Q[0], Q[1]: the generator fills one while the other is being
 // traced and shaded); the shading-point queue, the contribution slots and the per-view data are shared.
-int fast_alloc(FastBuffers Q[2], size_t pixels, int batch, PtAllocFn alloc, void *ctx) {
+int fast_alloc(FastBuffers Q[2], size_t pixels, int batch, int n_light, PtAllocFn alloc, void *ctx) {
     size_t n = pixels * (size_t)batch;
-    if (n > 0xFFFFFF00u) return PT_ERR_LIMIT;
+    const size_t n_shadow = n * (size_t)(n_light < 0 ? 0 : n_light);       // a shadow ray per point and light (0: no shadow-ray queue)
+    if (n > 0xFFFFFF00u || n_shadow >= 0x80000000u) return PT_ERR_LIMIT;
     int rc;
 #define FA(q, field, type) if ((rc = alloc(ctx, n * sizeof(type), (void **)&q.field))) return rc
     for (int k = 0; k < 2; k++) {
@@ -685,10 +726,15 @@ int fast_alloc(FastBuffers Q[2], size_t pixels, int batch, PtAllocFn alloc, void
     }
     FA(Q[0], sp_pos, float4); FA(Q[0], sp_nrm, float4); FA(Q[0], sp_base, float4); FA(Q[0], contrib, float4);
 #undef FA
+    if (n_shadow) {
+        if ((rc = alloc(ctx, n_shadow * sizeof(float4), (void **)&Q[0].sh_o))) return rc;
+        if ((rc = alloc(ctx, n_shadow * sizeof(float4), (void **)&Q[0].sh_d))) return rc;
+    }
     if ((rc = alloc(ctx, 2 * sizeof(unsigned long long), (void **)&Q[0].totals))) return rc;
     if ((rc = alloc(ctx, 2 * sizeof(unsigned long long), (void **)&Q[0].work))) return rc;
     if ((rc = alloc(ctx, ((pixels + 63) / 64 * 4 + 2) * sizeof(uint32_t), (void **)&Q[0].tile_base))) return rc;
     Q[1].sp_pos = Q[0].sp_pos; Q[1].sp_nrm = Q[0].sp_nrm; Q[1].sp_base = Q[0].sp_base; Q[1].contrib = Q[0].contrib;
+    Q[1].sh_o = Q[0].sh_o; Q[1].sh_d = Q[0].sh_d;
     Q[1].totals = Q[0].totals; Q[1].work = Q[0].work; Q[1].tile_base = Q[0].tile_base;
     return PT_OK;
 }
@@ -758,6 +804,7 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         const FastBuffers &Q = QQ[pass & 1];
         const int s0 = pass * batch, nb = nsamples - s0 < batch ? nsamples - s0 : batch;
         if ((size_t)nb * P > Q.max_rays) return PT_ERR_LIMIT;
+        if (V.model == PT_MODEL_MAIN && (!Q.sh_o || S.n_light > 32)) return PT_ERR_LIMIT;     // the shadow-ray queue was not asked for
         if (pass + 1 < npass)
             if (int rc = generate(pass + 1)) return rc;
         unsigned sblocks = (unsigned)((P * nb + PT_APPEND_BLOCK - 1) / PT_APPEND_BLOCK);
@@ -785,6 +832,7 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
                 hipLaunchKernelGGL(k_shadow_gi<LaneStateQ>, dim3(tblocks), dim3(64), lds, s, S, Q, smask, tune.refill, chunk);
             else
                 hipLaunchKernelGGL(k_shadow_gi<LaneState>, dim3(tblocks), dim3(64), lds, s, S, Q, smask, tune.refill, chunk);
+            hipLaunchKernelGGL(k_light_sum, dim3((unsigned)((P * nb + 255) / 256)), dim3(256), 0, s, S, Q);
         } else {
             static const bool fused = !(getenv("PT_TUNE_FUSED_SUM") && atoi(getenv("PT_TUNE_FUSED_SUM")) == 0);
             if (fused) {

@@ -56,9 +56,12 @@ struct FastBuffers {
     float4 *hits;             // t, u, v, triangle index bits (-1: miss)
     float4 *sp_pos;           // shading points (MAIN model): position xyz, triangle index bits
     float4 *sp_nrm;           // normal xyz, queue index of the ray (bits)
-    float4 *sp_base;          // r1 * 0.6 * txt * albedo / pi, unused
+    float4 *sp_base;          // r1 * 0.6 * txt * albedo / pi, index bits of the point's first shadow ray
+    float4 *sh_o, *sh_d;      // shadow rays (MAIN model), a point's rays one after the other in light order: origin xyz, index bits of
+                              // the point's triangle | direction xyz, distance to the light -- replaced by 1.0f / 0.0f (light
+                              // visible / not) when the ray has been traced
     float4 *contrib;          // per queue entry: r1 * radiance of the sample ray
-    uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2] shadow rays traced
+    uint32_t *counts;         // [0] rays in the queue, [1] shading points, [2] shadow rays
     uint32_t *tile_base;      // per 8x8 tile in queue order: pixels with a primary hit before it (exclusive prefix sum; total at the end)
     unsigned long long *totals;   // [0] GI rays, [1] shadow rays of the view so far
     uint32_t *heads;          // queue heads of the closest-hit kernel, then of the shadow kernel (pt_persistent.h)
@@ -88,7 +91,7 @@ int hemisphere_samples(uint32_t seed, uint32_t view, uint32_t pixel, int n, doub
 // take 11 GB.  PT_TUNE_PASS_RAYS overrides it (tests use a small value to force several passes).
 #define PT_FAST_RAYS_PER_PASS (64u << 20)
 typedef int (*PtAllocFn)(void *ctx, size_t bytes, void **out);
-int fast_alloc(FastBuffers Q[2], size_t pixels, int batch, PtAllocFn alloc, void *ctx);
+int fast_alloc(FastBuffers Q[2], size_t pixels, int batch, int n_light, PtAllocFn alloc, void *ctx);
 // All GI passes of one view: fills F.gi_acc.  trace_ms / launches: device time and
 // count of the closest-hit traversal launches; rays / shadow: query counts.
 int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const FastBuffers Q[2], int nsamples, int batch,

@@ -360,6 +360,60 @@ def test_errors(gpu_scenes, host_scenes):
         d.nodes[0].left = keep
 
 
+def test_fast_gi_with_several_lights(host_scenes):
+    """The fp32 GI path of the main.cpp model queues one shadow ray per shading point and light that can add something and
+    sums the lights of a point in order afterwards.  cbox with five lights around its own (two of them on the far side
+    of most surfaces): the image stays as close to the fp64 path's as with one light, run to run it is the same bit for
+    bit.  More than 32 lights are refused by that
+    path with a limit error, not rendered wrongly; the fp64 path takes them."""
+    from pathtracing_amd import host
+    hs = host_scenes("cbox")
+    d = hs.desc()
+    c = cam_of(hs)
+    keep = (d.lights, d.n_light)
+    base = d.lights[0]
+
+    def with_lights(n):
+        arr = (host.PtLight * n)()
+        for k in range(n):
+            arr[k] = base
+            if k:
+                arr[k].pos[0] = base.pos[0] + 60.0 * ((k % 3) - 1)
+                arr[k].pos[1] = base.pos[1] - 40.0 * (k % 4)
+                arr[k].pos[2] = base.pos[2] + 50.0 * ((k % 5) - 2)
+                arr[k].mag = base.mag * 0.3
+        return arr
+
+    try:
+        arr = with_lights(6)
+        d.lights, d.n_light = arr, 6
+        sc = device.DeviceScene(d)
+        kw = dict(model=device.MODEL_MAIN, gi=True, spp=8, size=128)
+        a = sc.render(**c, **kw, gi_precision=device.GI_F64_EXACT)
+        b = sc.render(**c, **kw, gi_precision=device.GI_F32_FAST)
+        b2 = sc.render(**c, **kw, gi_precision=device.GI_F32_FAST)
+        assert np.array_equal(b["rgb"], b2["rgb"])
+        diff = a["rgb"] - b["rgb"]
+        outlier = np.abs(diff).max(axis=2) > 0.01
+        assert outlier.sum() <= 10, int(outlier.sum())
+        assert float(np.sqrt(np.mean(diff[~outlier] ** 2))) < 3e-4
+        assert a["stats"]["gi"] == b["stats"]["gi"]
+        # the fp64 path traces a ray to every light as the reference does; the fp32 path leaves out lights behind the surface
+        assert 0.8 * a["stats"]["shadow"] < b["stats"]["shadow"] <= a["stats"]["shadow"]
+        assert b["stats"]["shadow"] > 1.5 * b["stats"]["gi"]        # the points have several of the six lights in front of them
+        sc.close()
+        arr = with_lights(33)
+        d.lights, d.n_light = arr, 33
+        sc = device.DeviceScene(d)
+        with pytest.raises(device.DeviceError, match="32 lights"):
+            sc.render(**c, model=device.MODEL_MAIN, gi=True, spp=2, size=32, gi_precision=device.GI_F32_FAST)
+        sc.render(**c, model=device.MODEL_MAIN, gi=True, spp=1, size=16, gi_precision=device.GI_F64_EXACT)
+        sc.render(**c, model=device.MODEL_OMP, gi=True, spp=2, size=32, gi_precision=device.GI_F32_FAST)
+        sc.close()
+    finally:
+        d.lights, d.n_light = keep
+
+
 @pytest.fixture(scope="module")
 def atrium_small(tmp_path_factory):
     """A 20 000-triangle atrium (procedural, per-hit textures, deep tree): host scene, oracle scene, GPU scene."""
