@@ -553,6 +553,12 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
                 const long long k = atoll(e);
                 if (k >= 1 && k <= (long long)(128u << 20)) cap = (size_t)k;
             }
+        // main.cpp model: a pass also queues a shadow ray per shading point and light; passes shrink past 16 lights
+        // so that that queue stays below 2^30 entries
+        if (fast && o->model == PT_MODEL_MAIN && sc->S.n_light > 16) {
+            const size_t most = ((size_t)1 << 30) / (size_t)sc->S.n_light;
+            if (cap > most) cap = most;
+        }
         batch = (int)(cap / P);
         if (batch < 1) batch = 1;
         if (batch > N) batch = N;

@@ -402,6 +402,17 @@ def test_fast_gi_with_several_lights(host_scenes):
         assert 0.8 * a["stats"]["shadow"] < b["stats"]["shadow"] <= a["stats"]["shadow"]
         assert b["stats"]["shadow"] > 1.5 * b["stats"]["gi"]        # the points have several of the six lights in front of them
         sc.close()
+        arr = with_lights(32)                                        # the most that path takes: every bit of its light mask
+        d.lights, d.n_light = arr, 32
+        sc = device.DeviceScene(d)
+        kw = dict(model=device.MODEL_MAIN, gi=True, spp=2, size=64)
+        a = sc.render(**c, **kw, gi_precision=device.GI_F64_EXACT)
+        b = sc.render(**c, **kw, gi_precision=device.GI_F32_FAST)
+        diff = a["rgb"] - b["rgb"]
+        outlier = np.abs(diff).max(axis=2) > 0.02
+        assert outlier.sum() <= 5, int(outlier.sum())
+        assert float(np.sqrt(np.mean(diff[~outlier] ** 2))) < 1e-3
+        sc.close()
         arr = with_lights(33)
         d.lights, d.n_light = arr, 33
         sc = device.DeviceScene(d)
