@@ -449,9 +449,9 @@ __device__ __forceinline__ float4 omp_contribution(const DevScene &S, float ox, 
     return make_float4(k * ar * dr, k * ag * dg, k * ab * db, 0.f);
 }
 
-// main.cpp:60-66 for light k at a shading point (position xyz | triangle, normal xyz): direction and distance of the
-// shadow ray and cos * radiance of the light; false when no ray is traced because the light adds nothing whatever the
-// ray says -- it is behind the surface, or the triangle the ray starts on shadows it.  The reference starts the ray
+// main.cpp:60-66 for light k at a shading point (position xyz | triangle, normal xyz): direction and length of the
+// shadow ray; false when no ray is traced because the light adds nothing whatever the ray says -- it is behind the
+// surface, or the triangle the ray starts on shadows it.  The reference starts the ray
 // 1e-4 along the shading normal and tests it against that triangle as well (main.cpp:63-66): the triangle shadows the
 // point when the light is on the other side of its plane than the shading normal.  Decided here by signs; the search
 // skips the triangle.

@@ -413,6 +413,13 @@ def test_fast_gi_with_several_lights(host_scenes):
         assert outlier.sum() <= 5, int(outlier.sum())
         assert float(np.sqrt(np.mean(diff[~outlier] ** 2))) < 1e-3
         sc.close()
+        d.n_light = 0                                                # no light at all: nothing to queue, a black but valid frame
+        sc = device.DeviceScene(d)
+        kw = dict(model=device.MODEL_MAIN, gi=True, spp=2, size=32)
+        a = sc.render(**c, **kw, gi_precision=device.GI_F64_EXACT)
+        b = sc.render(**c, **kw, gi_precision=device.GI_F32_FAST)
+        assert np.array_equal(a["rgb"], b["rgb"]) and b["stats"]["shadow"] == 0
+        sc.close()
         arr = with_lights(33)
         d.lights, d.n_light = arr, 33
         sc = device.DeviceScene(d)
