@@ -513,6 +513,7 @@ int ensure_workspace(PtScene *sc, int size, int batch, bool fast, int nsub, bool
     WS(ws_alloc(ws, P * nsub, &ws.B.found));
     WS(ws_alloc(ws, P * nsub, &ws.B.tri));
     WS(ws_alloc(ws, P * nsub * 3, &ws.B.tuv));
+    WS(ws_alloc(ws, P * nsub, &ws.B.again));
     WS(ws_alloc(ws, P * nsub, &ws.B.mirror));
     WS(ws_alloc(ws, P * nsub * 3, &ws.B.mdir));
     if (fast) WS(fast_alloc(ws.Q, P, batch, shadow ? (sc->S.n_light > 1 ? sc->S.n_light : 1) : 0, ws_alloc_cb, &ws));

@@ -341,21 +341,15 @@ struct PrimRec { int32_t found, tri; double t, u, v; };
 // What castRay computes of a hit before its mirror bounce: search, surface properties, hit point, the light loop.
 struct CastHit { HitD h; D3 nrm, txt, hit, direct, alb; int reft; };
 
-// The first part of castRay, main.cpp:41-66 (MODEL == PT_MODEL_MAIN) / mainOMP.cpp:37-63 (PT_MODEL_OMP):
-// false on a miss (c.h then holds the search's record).
+// castRay after its search found the hit c.h: surface properties, hit point, the light loop
+// (main.cpp:51-66 for MODEL == PT_MODEL_MAIN, mainOMP.cpp:47-63 for PT_MODEL_OMP).
+// retrace_clear (mainOMP model): the search of mainOMP.cpp:60 is known to find nothing (SearchNote).
 template <int MODEL>
-PT_DEV bool cast_hit(const DevScene &S, const RayD &ray, StackD &st, RayCounts &rc, CastHit &c) {
+PT_DEV void cast_lights(const DevScene &S, const RayD &ray, StackD &st, RayCounts &rc, CastHit &c, bool retrace_clear) {
     HitD &h = c.h;
-    h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
-    SearchNote note;
-    bool ok = MODEL == PT_MODEL_OMP ? search_ref_t<true>(S, ray, h, &note, st) : search_ref(S, ray, h, st);
-    if (!ok) return false;
     c.nrm = surface_normal(S, h.tri, h.u, h.v);
     c.hit = dadd(dadd(ray.src, dscale(h.tmin, ray.dir)), dscale(0.0001, c.nrm));
     D3 direct = d3(0, 0, 0);
-    // mainOMP.cpp:60: known to find nothing -- by the note of the first search, or because the last one found nothing
-    // and so left h as it was, which makes the next one the same search
-    bool retrace_clear = MODEL == PT_MODEL_OMP && !note.may_find_closer(h.tmin);
     for (int k = 0; k < S.n_light; k++) {
         // Light::illuminate (util/lighting.cpp:24-36) around the visibility search: direction and distance before it,
         // the radiance after it (a function of the light and the distance only), so that it is not held in registers
@@ -369,6 +363,8 @@ PT_DEV bool cast_hit(const DevScene &S, const RayD &ray, StackD &st, RayCounts &
             vis = !search_ref(S, lray, sh, st);
             rc.n[RC_SHADOW]++;
         } else {                                             // mainOMP.cpp:60: re-traces `ray` bounded by its own hit
+            // known to find nothing by the note of the first search, or because the last one found nothing and so left
+            // h as it was, which makes the next one the same search
             if (!retrace_clear) retrace_clear = !search_ref(S, ray, h, st);
             vis = retrace_clear;
             rc.n[RC_RETRACE]++;
@@ -381,6 +377,18 @@ PT_DEV bool cast_hit(const DevScene &S, const RayD &ray, StackD &st, RayCounts &
     surface_texture(S, h.tri, h.u, h.v, c.txt, c.reft);
     const double *ap = S.albedo + (size_t)S.tri_mesh[h.tri] * 3;
     c.alb = d3(ap[0], ap[1], ap[2]);
+}
+
+// The first part of castRay, main.cpp:41-66 (MODEL == PT_MODEL_MAIN) / mainOMP.cpp:37-63 (PT_MODEL_OMP):
+// false on a miss (c.h then holds the search's record).
+template <int MODEL>
+PT_DEV bool cast_hit(const DevScene &S, const RayD &ray, StackD &st, RayCounts &rc, CastHit &c) {
+    HitD &h = c.h;
+    h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
+    SearchNote note;
+    bool ok = MODEL == PT_MODEL_OMP ? search_ref_t<true>(S, ray, h, &note, st) : search_ref(S, ray, h, st);
+    if (!ok) return false;
+    cast_lights<MODEL>(S, ray, st, rc, c, MODEL == PT_MODEL_OMP && !note.may_find_closer(h.tmin));
     return true;
 }
 

@@ -6,6 +6,7 @@
 // Build with -ffp-contract=off.
 #include "pt_exact.h"
 #include "pt_frame.h"
+#include "pt_packet.h"
 
 // 8x8 pixel tiles: one wave = one tile, so that the rays of a wave stay close.
 PT_DEV bool tile_pixel(int linear, int size, int &i, int &j) {
@@ -30,23 +31,84 @@ PT_DEV void flush_counts(const RayCounts &rc, unsigned long long *counters) {
     }
 }
 
-// Primary pass, one thread per sub-ray.  Without -rb a wave is one 8x8 pixel tile.  With
-// -rb every sub-ray of a bundle is its own thread and the nine sub-rays of a pixel sit in
-// adjacent lanes (7 pixels x 9 = 63 lanes of a wave, one lane idle): they differ by a
-// hundredth of a pixel, so they walk the tree together.  The sub-ray results are folded
-// into the frame buffers by k_primary_combine in the reference's order.
+// Which pixel and sub-ray lane `lane` of work block `blk` of the primary search handles.  A work block is a packet of
+// camera rays that the wave searches together (pt_packet.h): with -rb the nine sub-rays of each of 7 neighbouring pixels
+// of one image row (63 lanes, one idle; the last packet of a row may hold fewer pixels), otherwise an 8x8 pixel tile.
+PT_DEV bool packet_pixel(const ViewParams &V, uint32_t blk, uint32_t lane, int &i, int &j, int &sub) {
+    if (V.rb) {
+        const uint32_t segs = ((uint32_t)V.size + 6u) / 7u;
+        const uint32_t row = blk / segs, seg = blk - row * segs, px = lane / 9u;
+        sub = (int)(lane - px * 9u);
+        i = (int)row; j = (int)(seg * 7u + px);
+        return lane < 63u && j < V.size;
+    }
+    sub = 4;
+    return tile_pixel((int)(blk * 64u + lane), V.size, i, j);
+}
+static inline unsigned packet_blocks(int size, int rb) {
+    return rb ? (unsigned)size * (((unsigned)size + 6u) / 7u) : (unsigned)(tile_threads(size) / 64);
+}
+
+// The camera ray of sub-ray `sub` of pixel (i, j): the offsets as the reference's loops produce them,
+// -o, -o + o, (-o + o) + o  (main.cpp:116-117).
+PT_DEV RayD sub_ray(const ViewParams &V, int i, int j, int sub) {
+    const double o0 = -V.off, o1 = o0 + V.off, o2 = o1 + V.off;
+    const int xi = sub % 3, yi = sub / 3;
+    const double x = xi == 0 ? o0 : (xi == 1 ? o1 : o2), y = yi == 0 ? o0 : (yi == 1 ? o1 : o2);
+    return camera_ray(d3(V.eye[0], V.eye[1], V.eye[2]), V.zoom, V.sa, V.ca, V.size, i, j, x, y);
+}
+
+// Primary pass, first kernel: the search of castRay at depth 0 (main.cpp:43 / mainOMP.cpp:39) for every sub-ray, one
+// packet per wave.  Writes the hit record of each sub-ray and, for the mainOMP model, whether the second search of
+// mainOMP.cpp:60 has to be run (SearchNote); k_primary_shade does the rest of castRay from that record.
 template <int MODEL>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_primary_exact(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B, uint32_t nblocks) {
+__global__ void __launch_bounds__(64) k_primary_search(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B, uint32_t nblocks) {
+    extern __shared__ double stack_lds[];
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t nprimary = 0;
+    // persistent waves: a launched block (it owns a region of the stack overflow buffer) draws work blocks from a counter
+    for (;;) {
+        uint32_t blk = 0;
+        if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_PRIMARY], 1ull);
+        blk = __builtin_amdgcn_readfirstlane(blk);
+        if (blk >= nblocks) break;
+        int i = 0, j = 0, sub = 4;
+        const bool live = packet_pixel(V, blk, lane, i, j, sub) && own_row(V.part, V.n_parts, i);
+        if (!__ballot(live)) continue;
+        const RayD ray = sub_ray(V, i, j, sub);      // lanes that are not live get a ray too: same origin, never searched
+        const PacketBounds PB = packet_bounds(V.sa, V.ca, ray.dir, live);
+        HitD h;
+        h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
+        SearchNote note;
+        const bool ok = MODEL == PT_MODEL_OMP ? packet_search<true>(S, ray, live, PB, h, &note, stack_lds)
+                                              : packet_search<false>(S, ray, live, PB, h, nullptr, stack_lds);
+        if (!live) continue;
+        nprimary++;
+        const size_t p = (size_t)i * V.size + j, slot = V.rb ? p * 9 + sub : p;
+        B.found[slot] = ok ? 1 : 0; B.tri[slot] = ok ? h.tri : -1;
+        B.tuv[3 * slot] = ok ? h.tmin : -1.0; B.tuv[3 * slot + 1] = h.u; B.tuv[3 * slot + 2] = h.v;
+        B.again[slot] = MODEL == PT_MODEL_OMP && ok && note.may_find_closer(h.tmin) ? 1 : 0;
+    }
+    const uint32_t total = wave_sum(nprimary);
+    if (lane == 0 && total) atomicAdd(&F.counters[RC_PRIMARY], (unsigned long long)total);
+}
+
+// Primary pass, second kernel, one thread per sub-ray: castRay at depth 0 after its search (main.cpp:44-78 /
+// mainOMP.cpp:40-78) up to its mirror bounce.  Without -rb a wave is one 8x8 pixel tile; with -rb the nine sub-rays of
+// a pixel sit in adjacent lanes (7 pixels x 9 = 63 lanes of a wave, one lane idle).  A reflective hit leaves
+// a = 0.6 txt albedo direct / pi in `paint` and its mirror ray's direction in `mdir`; k_mirror_exact adds the bounce.
+// The sub-ray results are folded into the frame buffers by k_primary_combine in the reference's order.
+template <int MODEL>
+__global__ void __launch_bounds__(64) k_primary_shade(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B, uint32_t nblocks) {
     extern __shared__ double stack_lds[];
     StackD st = make_stack(S, stack_lds);
     RayCounts rc;
 #pragma unroll
     for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
     const uint32_t lane = threadIdx.x & 63;
-    // persistent waves: a launched block (it owns a region of the stack overflow buffer) draws work blocks from a counter
     for (;;) {
         uint32_t blk = 0;
-        if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_PRIMARY], 1ull);
+        if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_SHADE], 1ull);
         blk = __builtin_amdgcn_readfirstlane(blk);
         if (blk >= nblocks) break;
         uint32_t lin;
@@ -64,28 +126,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
         live = live && tile_pixel((int)lin, V.size, i, j) && own_row(V.part, V.n_parts, i);
         if (!live) continue;
         const size_t p = (size_t)i * V.size + j, slot = V.rb ? p * 9 + sub : p;
-        // the offsets as the reference's loops produce them: -o, -o + o, (-o + o) + o  (main.cpp:116-117)
-        const double o0 = -V.off, o1 = o0 + V.off, o2 = o1 + V.off;
-        const int xi = sub % 3, yi = sub / 3;
-        const double x = xi == 0 ? o0 : (xi == 1 ? o1 : o2), y = yi == 0 ? o0 : (yi == 1 ? o1 : o2);
-        RayD ray = camera_ray(d3(V.eye[0], V.eye[1], V.eye[2]), V.zoom, V.sa, V.ca, V.size, i, j, x, y);
-        rc.n[RC_PRIMARY]++;
-        // castRay at depth 0 (main.cpp:41-78 / mainOMP.cpp:37-78) up to its mirror bounce.  The G-buffer candidate and
-        // the hit record go to memory as soon as they are known.  A reflective hit leaves a = 0.6 txt albedo direct / pi
-        // in `paint` and its mirror ray's direction in `mdir`; k_mirror_exact adds the bounce.
-        CastHit c;
         D3 paint;
         int mirror = 0;
-        if (!cast_hit<MODEL>(S, ray, st, rc, c)) {
+        if (!B.found[slot]) {
             const D3 zero = d3(0, 0, 0);
             dstore(B.g + 9 * slot, zero); dstore(B.g + 9 * slot + 3, zero); dstore(B.g + 9 * slot + 6, d3(-99999, -99999, -99999));
-            B.found[slot] = 0; B.tri[slot] = -1;
-            B.tuv[3 * slot] = -1.0; B.tuv[3 * slot + 1] = c.h.u; B.tuv[3 * slot + 2] = c.h.v;
             paint = d3(S.bg[0], S.bg[1], S.bg[2]);
         } else {
+            const RayD ray = sub_ray(V, i, j, sub);
+            CastHit c;
+            c.h.tri = B.tri[slot]; c.h.tmin = B.tuv[3 * slot]; c.h.u = B.tuv[3 * slot + 1]; c.h.v = B.tuv[3 * slot + 2];
+            cast_lights<MODEL>(S, ray, st, rc, c, MODEL == PT_MODEL_OMP && !B.again[slot]);
+            // the G-buffer candidate goes to memory as soon as it is known
             dstore(B.g + 9 * slot, dmul(c.txt, c.alb)); dstore(B.g + 9 * slot + 3, c.nrm); dstore(B.g + 9 * slot + 6, c.hit);
-            B.found[slot] = 1; B.tri[slot] = c.h.tri;
-            B.tuv[3 * slot] = c.h.tmin; B.tuv[3 * slot + 1] = c.h.u; B.tuv[3 * slot + 2] = c.h.v;
+            if (MODEL == PT_MODEL_OMP) {             // a second search that did find something closer moved the record (mainOMP.cpp:60)
+                B.tri[slot] = c.h.tri;
+                B.tuv[3 * slot] = c.h.tmin; B.tuv[3 * slot + 1] = c.h.u; B.tuv[3 * slot + 2] = c.h.v;
+            }
             if (c.reft) {
                 mirror = 1;
                 paint = ddivs(dmul(dmul(dscale(0.6, c.txt), c.alb), c.direct), 3.14159265358979323846);
@@ -300,14 +357,19 @@ int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F,
     const size_t P = (size_t)V.size * V.size;
     const unsigned cblocks = (unsigned)((P + 255) / 256);
     const unsigned blocks = V.rb ? (unsigned)(((size_t)tile_threads(V.size) * 9 + 62) / 63) : (unsigned)(tile_threads(V.size) / 64);
+    const unsigned pblocks = packet_blocks(V.size, V.rb);
     if (V.model == PT_MODEL_MAIN) {
-        static const unsigned wp = resident_waves(k_primary_exact<PT_MODEL_MAIN>, PT_EXACT_WAVES), wm = resident_waves(k_mirror_exact<PT_MODEL_MAIN>, PT_EXACT_WAVES);
-        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_MAIN>, dim3(blocks < wp ? blocks : wp), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
+        static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_MAIN>, PT_EXACT_WAVES), wp = resident_waves(k_primary_shade<PT_MODEL_MAIN>, PT_EXACT_WAVES),
+                              wm = resident_waves(k_mirror_exact<PT_MODEL_MAIN>, PT_EXACT_WAVES);
+        hipLaunchKernelGGL(k_primary_search<PT_MODEL_MAIN>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, pblocks);
+        hipLaunchKernelGGL(k_primary_shade<PT_MODEL_MAIN>, dim3(blocks < wp ? blocks : wp), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         if (S.any_mirror) hipLaunchKernelGGL(k_mirror_exact<PT_MODEL_MAIN>, dim3(blocks < wm ? blocks : wm), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         hipLaunchKernelGGL(k_primary_combine<PT_MODEL_MAIN>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb, V.part, V.n_parts);
     } else {
-        static const unsigned wp = resident_waves(k_primary_exact<PT_MODEL_OMP>, PT_EXACT_WAVES), wm = resident_waves(k_mirror_exact<PT_MODEL_OMP>, PT_EXACT_WAVES);
-        hipLaunchKernelGGL(k_primary_exact<PT_MODEL_OMP>, dim3(blocks < wp ? blocks : wp), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
+        static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_OMP>, PT_EXACT_WAVES), wp = resident_waves(k_primary_shade<PT_MODEL_OMP>, PT_EXACT_WAVES),
+                              wm = resident_waves(k_mirror_exact<PT_MODEL_OMP>, PT_EXACT_WAVES);
+        hipLaunchKernelGGL(k_primary_search<PT_MODEL_OMP>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, pblocks);
+        hipLaunchKernelGGL(k_primary_shade<PT_MODEL_OMP>, dim3(blocks < wp ? blocks : wp), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         if (S.any_mirror) hipLaunchKernelGGL(k_mirror_exact<PT_MODEL_OMP>, dim3(blocks < wm ? blocks : wm), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         hipLaunchKernelGGL(k_primary_combine<PT_MODEL_OMP>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb, V.part, V.n_parts);
     }

@@ -44,6 +44,7 @@ struct SubBuffers {
     double *g;                 // 9: mclr, mnrm, mhit candidate
     int32_t *found, *tri;
     double *tuv;               // 3: t, u, v
+    int32_t *again;            // mainOMP model: the second search of mainOMP.cpp:60 has to be run for this sub-ray
     int32_t *mirror;           // the hit is reflective: `paint` holds the hit's own term until the bounce is added
     double *mdir;              // 3: direction of the mirror ray (its origin is the hit point in `g`)
 };

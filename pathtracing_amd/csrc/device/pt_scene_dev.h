@@ -83,4 +83,4 @@ struct DevScene {
     X(tri_mesh) X(tri_local) X(norm) X(uv) X(albedo) X(triShadeF) X(texels) X(tex_off) X(tex_rows) X(tex_cols) X(lights) X(lightsF)
 
 enum { PT_LIMIT_F32_STACK = 1, PT_LIMIT_F32_STEPS = 2, PT_LIMIT_F64_STACK = 4 };
-enum { RC_PRIMARY = 0, RC_SHADOW = 1, RC_MIRROR = 2, RC_GI = 3, RC_RETRACE = 4, RC_WORK_PRIMARY = 5, RC_WORK_MIRROR = 6, RC_LIMITS = 7, RC_N = 8 };
+enum { RC_PRIMARY = 0, RC_SHADOW = 1, RC_MIRROR = 2, RC_GI = 3, RC_RETRACE = 4, RC_WORK_PRIMARY = 5, RC_WORK_MIRROR = 6, RC_LIMITS = 7, RC_WORK_SHADE = 8, RC_N = 9 };

@@ -1,0 +1,260 @@
+/*
+ * Test helper (built by tests/test_packet_rule.py, never by the product): a CPU model of the device's packet search,
+ * checked ray by ray against the oracle's search() restatement.
+ *
+ * The device searches the camera rays of one wave -- up to 64 rays that leave the same point -- as ONE packet: the
+ * wave stands in one node at a time, a mask says which rays are in it, and the rays that part ways wait in a stack
+ * entry until the wave comes back for them.  Each ray still makes exactly the decisions of util/kdtree.cpp:216-257 on
+ * its own numbers, and meets its nodes and triangles in the order of its own search.  Before the rays of the packet
+ * test the triangles of a node, the packet as a whole is tested against them (one triangle per lane): a triangle that
+ * provably none of the packet's rays can hit is left out.  This file states both parts in plain C:
+ *     packet_search()   the walk, with the notes the device keeps for mainOMP.cpp:60 (see research_check.c)
+ *     packet_cull()     the conservative packet-vs-triangle test
+ * and packet_check() runs them on the camera rays of a view, packets formed as the device forms them, and counts every
+ * ray whose result differs from search_ref()/search_noted() in any bit.
+ */
+#include <stddef.h>
+
+#include "research_check.c"
+
+#define PW 64
+typedef unsigned long long u64;
+
+typedef struct {
+    long packets, rays, node_visits, lists, list_entries, survivors, lane_tests, any_pass, pushes, pops, max_depth;
+    long ref_node_visits, ref_tri_tests;
+    long depth_hist[64];
+} PStats;
+
+/* Bounds of a packet's directions in a frame (d0, a, b): every direction d of the packet satisfies
+   d = c d0 + al a + be b + r  with c in [c0, c1], al in [a0, a1], be in [b0, b1] and |r|_2 <= rr. */
+typedef struct { V3 d0, a, b; double c0, c1, a0, a1, b0, b1, rr; } Bundle;
+
+/* The frame is the camera's (forward, right, up of main.cpp:119-120), in which a packet of neighbouring pixels is an
+   axis-aligned box; any frame gives valid bounds, since the remainder r is measured, not assumed. */
+static Bundle bundle_of(const Ray *rays, u64 live, double sa, double ca) {
+    Bundle B; memset(&B, 0, sizeof B);
+    B.d0 = v3(ca, 0, sa); B.a = v3(sa, 0, -ca); B.b = v3(0, 1, 0);
+    B.c0 = B.a0 = B.b0 = INFINITY; B.c1 = B.a1 = B.b1 = -INFINITY;
+    for (int l = 0; l < PW; l++) if (live >> l & 1) {
+        V3 d = rays[l].dir;
+        double c = vdot(d, B.d0), al = vdot(d, B.a), be = vdot(d, B.b);
+        V3 r = vsub(d, vadd(vadd(vscale(c, B.d0), vscale(al, B.a)), vscale(be, B.b)));
+        double rr = vlen(r);
+        if (c < B.c0) B.c0 = c; if (c > B.c1) B.c1 = c;
+        if (al < B.a0) B.a0 = al; if (al > B.a1) B.a1 = al;
+        if (be < B.b0) B.b0 = be; if (be > B.b1) B.b1 = be;
+        if (rr > B.rr) B.rr = rr;
+    }
+    B.rr = 2.0 * B.rr + 1e-15;
+    return B;
+}
+
+static inline double l1(V3 a) { return fabs(a.x) + fabs(a.y) + fabs(a.z); }
+static inline void form_range(const Bundle *B, V3 A, double *lo, double *hi) {
+    double f0 = vdot(B->d0, A), fa = vdot(B->a, A), fb = vdot(B->b, A);
+    double x0 = B->c0 * f0, x1 = B->c1 * f0, y0 = B->a0 * fa, y1 = B->a1 * fa, z0 = B->b0 * fb, z1 = B->b1 * fb;
+    double r = B->rr * l1(A);
+    *lo = fmin(x0, x1) + fmin(y0, y1) + fmin(z0, z1) - r;
+    *hi = fmax(x0, x1) + fmax(y0, y1) + fmax(z0, z1) + r;
+}
+
+/* 1: no ray of the packet (origin o, directions bounded by B) can pass the reference's tests on this triangle. */
+static int packet_cull(const Bundle *B, V3 o, V3 v0, V3 e1, V3 e2) {
+    const double K = 1e-12;
+    V3 T = vsub(o, v0);
+    V3 Nn = vcross(e2, e1), A = vcross(e2, T), Bv = vcross(T, e1);
+    V3 Cw = vsub(vadd(A, Bv), Nn);
+    double tn = vdot(Bv, e2);
+    double n1 = l1(e1), n2 = l1(e2), nT = l1(T);
+    double Md = 2.0 * n1 * n2, Mu = 2.0 * n2 * nT, Mv = 2.0 * nT * n1, Mt = nT * n1 * n2;
+    if (!(Md >= 1e-100 && Md <= 1e100 && Mu >= 1e-100 && Mu <= 1e100 && Mv >= 1e-100 && Mv <= 1e100 && Mt <= 1e100)) return 0;
+    double md = K * Md, mu = K * Mu, mv = K * Mv, mw = K * (Md + Mu + Mv), mt = K * Mt;
+    double dlo, dhi, ulo, uhi, vlo, vhi, wlo, whi;
+    form_range(B, Nn, &dlo, &dhi);
+    int pos = dlo > md, neg = dhi < -md;
+    if (!pos && !neg) return 0;
+    form_range(B, A, &ulo, &uhi);
+    form_range(B, Bv, &vlo, &vhi);
+    form_range(B, Cw, &wlo, &whi);
+    if (pos) return uhi < -mu || vhi < -mv || wlo > mw || tn < -mt;
+    return ulo > mu || vlo > mv || whi < -mw || tn > mt;
+}
+
+typedef struct { const KD *node; u64 push, defer; double ent[PW], ext[PW]; } PEntry;
+
+/* One node's list for the rays in `act`; returns the mask of rays that improved their hit here. */
+static u64 packet_node(const Scene *s, const KD *nd, const Ray *rays, u64 act, const Bundle *B, Hit *h, PStats *ps, int cull) {
+    u64 improved = 0;
+    ps->lists++;
+    for (int i = 0; i < nd->n; i++) {
+        const Mesh *me = &s->mesh[nd->m[i]];
+        ps->list_entries++;
+        if (cull) {
+            const int *V = me->tris[nd->t[i]].vi;
+            V3 v0 = me->vert[V[0]];
+            if (packet_cull(B, rays[__builtin_ctzll(act)].src, v0, vsub(me->vert[V[1]], v0), vsub(me->vert[V[2]], v0))) continue;
+        }
+        ps->survivors++;
+        int any = 0;
+        for (int l = 0; l < PW; l++) if (act >> l & 1) {
+            double t, bu, bv;
+            ps->lane_tests++;
+            if (tri_intersect(me, nd->t[i], &rays[l], &t, &bu, &bv)) {
+                any = 1;
+                if (t > 0 && t < h[l].tmin) {
+                    V3 hit = vadd(rays[l].src, vscale(t, rays[l].dir));
+                    if (!(hit.x >= nd->lo.x && hit.y >= nd->lo.y && hit.z >= nd->lo.z &&
+                          hit.x <= nd->hi.x && hit.y <= nd->hi.y && hit.z <= nd->hi.z))
+                        continue;
+                    improved |= 1ull << l;
+                    h[l].tmin = t; h[l].u = bu; h[l].v = bv; h[l].m = nd->m[i]; h[l].t = nd->t[i];
+                }
+            }
+        }
+        ps->any_pass += any;
+    }
+    return improved;
+}
+
+/* The packet walk.  rays[l] for l in live share their origin.  ret[l] = what search() returns for ray l. */
+static void packet_search(const Scene *s, const Ray *rays, u64 live, double sa, double ca, Hit *h, int *ret, Note *note, PStats *ps, int cull) {
+    static _Thread_local PEntry stack[STK];
+    double ent[PW], ext[PW];
+    u64 act = 0, done = ~live, found = 0;
+    int sp = 0;
+    const KD *curr = s->root;
+    Bundle B = bundle_of(rays, live, sa, ca);
+    for (int l = 0; l < PW; l++) {
+        ret[l] = 0;
+        note[l].far_max = -INFINITY; note[l].stack_min = INFINITY;
+        if (!(live >> l & 1)) continue;
+        if (box_intersect(curr->lo, curr->hi, &rays[l], &ent[l], &ext[l]) && !(ent[l] >= h[l].tmin)) act |= 1ull << l;
+        else done |= 1ull << l;
+    }
+    ps->packets++;
+    for (;;) {
+        if (!act) {
+            while (sp > 0 && !act) {
+                const PEntry *e = &stack[--sp];
+                ps->pops++;
+                for (int l = 0; l < PW; l++) {
+                    if (e->push >> l & 1) {
+                        if (done >> l & 1) { if (e->ent[l] < note[l].stack_min) note[l].stack_min = e->ent[l]; }
+                        else if (e->ent[l] >= h[l].tmin) done |= 1ull << l;        /* util/kdtree.cpp:229-231 */
+                        else { ent[l] = e->ent[l]; ext[l] = e->ext[l]; act |= 1ull << l; }
+                    } else if (e->defer >> l & 1) act |= 1ull << l;
+                }
+                curr = e->node;
+            }
+            if (!act) break;
+        }
+        ps->node_visits++;
+        u64 improved = curr->n > 0 ? packet_node(s, curr, rays, act, &B, h, ps, cull) : 0;
+        if (curr->leaf) {
+            for (int l = 0; l < PW; l++) if (improved >> l & 1) ret[l] = 1;
+            done |= improved;
+            act = 0;
+            continue;
+        }
+        found |= improved;
+        u64 nearm = 0, faronly = 0, pushm = 0;
+        double tmidv[PW];
+        const int a = curr->axis;
+        const double sp_ = curr->splt;
+        const int swap = vget(rays[__builtin_ctzll(act)].src, a) > sp_;
+        for (int l = 0; l < PW; l++) if (act >> l & 1) {
+            double da = vget(rays[l].dir, a);
+            double tdir = da == 0 ? 0.0000001 : da;
+            double tmid = (sp_ - vget(rays[l].src, a)) / tdir;
+            tmidv[l] = tmid;
+            if (tmid >= ext[l] || tmid < 0) nearm |= 1ull << l;
+            else if (tmid <= ent[l] && tmid <= h[l].tmin) {
+                faronly |= 1ull << l;
+                if (tmid > note[l].far_max) note[l].far_max = tmid;
+            } else {
+                nearm |= 1ull << l;
+                if (tmid <= h[l].tmin) pushm |= 1ull << l;
+            }
+        }
+        const KD *nr = swap ? curr->right : curr->left, *fr = swap ? curr->left : curr->right;
+        if (nearm) {
+            if (faronly | pushm) {
+                if (sp >= STK) { fprintf(stderr, "packet: stack overflow\n"); abort(); }
+                PEntry *e = &stack[sp++];
+                e->node = fr; e->push = pushm; e->defer = faronly;
+                for (int l = 0; l < PW; l++) if (pushm >> l & 1) { e->ent[l] = tmidv[l]; e->ext[l] = ext[l]; }
+                ps->pushes++;
+                if (sp > ps->max_depth) ps->max_depth = sp;
+            }
+            /* the rays that take the near child with the far one to follow (pushed or, beyond their hit, dropped) */
+            for (int l = 0; l < PW; l++)
+                if ((nearm >> l & 1) && !(tmidv[l] >= ext[l] || tmidv[l] < 0)) ext[l] = tmidv[l];
+            curr = nr; act = nearm;
+        } else {
+            curr = fr; act = faronly;
+        }
+        ps->depth_hist[sp < 63 ? sp : 63]++;
+    }
+    for (int l = 0; l < PW; l++) if ((live >> l & 1) && !ret[l]) ret[l] = (int)(found >> l & 1);
+}
+
+/* Camera rays of one view in the device's packets: with rb, strips of 7 pixels of a row x 9 sub-rays (63 lanes);
+   without, 8x8 pixel tiles.  Rows row0, row0 + row_step, ... (tiles: tile rows).  out: [0] rays, [1] rays whose result
+   differs from search_ref (must be 0), [2] rays whose notes differ from search_noted (must be 0), then the PStats. */
+void packet_check(const Scene *s, const double eye[3], double angle, double zoom, int size, int rb, double off,
+                  int row0, int row_step, int cull, long *out, PStats *stats) {
+    V3 src = v3(eye[0], eye[1], eye[2]);
+    double sa = sin(angle), ca = cos(angle);
+    long n_rays = 0, n_diff = 0, n_note = 0;
+    PStats total; memset(&total, 0, sizeof total);
+    const int nrows = rb ? size : (size + 7) / 8;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : n_rays, n_diff, n_note)
+    for (int r = row0; r < nrows; r += row_step) {
+        PStats ps; memset(&ps, 0, sizeof ps);
+        const int nseg = rb ? (size + 6) / 7 : (size + 7) / 8;
+        for (int seg = 0; seg < nseg; seg++) {
+            Ray rays[PW]; u64 live = 0;
+            memset(rays, 0, sizeof rays);
+            for (int l = 0; l < PW; l++) {
+                int i, j; double x = 0, y = 0;
+                if (rb) {
+                    if (l >= 63) continue;
+                    int px = l / 9, sub = l % 9;
+                    i = r; j = seg * 7 + px;
+                    const double o0 = -off, o1 = o0 + off, o2 = o1 + off;
+                    const int xi = sub % 3, yi = sub / 3;
+                    x = xi == 0 ? o0 : (xi == 1 ? o1 : o2); y = yi == 0 ? o0 : (yi == 1 ? o1 : o2);
+                } else {
+                    i = r * 8 + (l >> 3); j = seg * 8 + (l & 7);
+                }
+                if (i >= size || j >= size) continue;
+                rays[l] = camera_ray(src, zoom, sa, ca, size, i, j, x, y);
+                live |= 1ull << l;
+            }
+            if (!live) continue;
+            Hit h[PW]; int ret[PW]; Note note[PW];
+            for (int l = 0; l < PW; l++) { h[l].tmin = FLT_MAX; h[l].m = h[l].t = -1; h[l].u = h[l].v = 0; }
+            packet_search(s, rays, live, sa, ca, h, ret, note, &ps, cull);
+            for (int l = 0; l < PW; l++) if (live >> l & 1) {
+                Hit a; Note na; Cnt c; memset(&c, 0, sizeof c);
+                a.tmin = FLT_MAX; a.m = a.t = -1; a.u = a.v = 0;
+                Hit b = a;
+                int fa = search_ref(s, &rays[l], &a, &c), fb = search_noted(s, &rays[l], &b, &na);
+                ps.ref_node_visits += c.node_visits; ps.ref_tri_tests += c.tri_tests;
+                n_rays++;
+                if (fa != ret[l] || memcmp(&a, &h[l], sizeof a) != 0) n_diff++;
+                if (fb != fa || na.far_max != note[l].far_max || na.stack_min != note[l].stack_min) n_note++;
+            }
+        }
+#pragma omp critical
+        {
+            long *t = (long *)&total, *p = (long *)&ps;
+            for (size_t k = 0; k < sizeof(PStats) / sizeof(long); k++)
+                if (k == offsetof(PStats, max_depth) / sizeof(long)) { if (p[k] > t[k]) t[k] = p[k]; } else t[k] += p[k];
+        }
+    }
+    total.rays = n_rays;
+    out[0] = n_rays; out[1] = n_diff; out[2] = n_note;
+    *stats = total;
+}

@@ -1,0 +1,91 @@
+"""The packet search of the primary pass (pathtracing_amd/csrc/device/pt_packet.h), checked on the CPU: tests/packet_check.c
+states the walk and the packet-vs-triangle test in plain C and compares every camera ray's result and notes with the
+oracle's own search, bit for bit.  A triangle that the packet test leaves out although some ray of the packet hits it
+would show up as a differing ray, so `differ == 0` is also the statement that the test never rejects wrongly."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, scene_path
+
+NAMES = "packets rays node_visits lists list_entries survivors lane_tests any_pass pushes pops max_depth ref_nodes ref_tris".split()
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    so = tmp_path_factory.mktemp("packet") / "packet_check.so"
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-o", str(so),
+                    os.path.join(ROOT, "tests", "packet_check.c"), "-lm"], check=True)
+    L = C.CDLL(str(so))
+    L.orc_scene_load.restype = C.c_void_p
+    L.orc_scene_load.argtypes = [C.c_char_p]
+    L.orc_build_tree.argtypes = [C.c_void_p]
+    L.orc_scene_camera.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_root_box.argtypes = [C.c_void_p, C.c_void_p]
+    L.packet_check.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                               C.c_int, C.c_void_p, C.c_void_p]
+    return L
+
+
+def run(L, h, eye, angle, zoom, size, rb, off, row_step, cull=1):
+    eye = np.ascontiguousarray(eye, np.float64)
+    out = np.zeros(3, np.int64)
+    st = np.zeros(len(NAMES) + 64, np.int64)
+    L.packet_check(h, eye.ctypes.data, angle, zoom, size, rb, off, 0, row_step, cull, out.ctypes.data, st.ctypes.data)
+    return out.tolist(), dict(zip(NAMES, st[:len(NAMES)].tolist()))
+
+
+@pytest.mark.parametrize("name", ["cbox", "car", "pine", "terrace", "atrium"])
+def test_packet_search_is_the_reference_search_for_every_camera_ray(checker, tmp_path, name):
+    path = scene_path(name) if name != "atrium" else str(tmp_path / "atrium.ptscene")
+    if name == "atrium":                     # the procedural hall at 20 000 triangles: a deep tree with thin cells
+        from pathtracing_amd import host
+        host.HostScene.atrium(20000, 12345).save_packed(path)
+    h = checker.orc_scene_load(os.fsencode(path))
+    assert h
+    checker.orc_build_tree(h)
+    cam = np.zeros(7)
+    checker.orc_scene_camera(h, cam.ctypes.data)
+    box = np.zeros(6)
+    checker.orc_root_box(h, box.ctypes.data)
+    centre = (box[:3] + box[3:]) / 2
+    total = 0
+    # the scene's own camera turned through a full circle, a camera at the centre of the scene's box and one outside it;
+    # with bundles (both offsets of the reference) and without; sizes that leave ragged packets at the image's edge
+    cases = []
+    for k in range(8):
+        cases.append((cam[:3], cam[5] + k * np.pi / 4, cam[6], 128, 1, 0.1 if k % 2 else 0.01, 5))
+        cases.append((cam[:3], cam[5] + k * np.pi / 4 + 0.3, cam[6], 96, 0, 0.0, 3))
+    cases.append((centre, 0.7, 1.0, 100, 1, 0.1, 4))
+    cases.append((centre, 2.9, 0.5, 61, 0, 0.0, 1))
+    cases.append((box[3:] + (box[3:] - box[:3]), cam[5], 2.0, 50, 1, 0.1, 2))
+    agg = dict.fromkeys(NAMES, 0)
+    for eye, angle, zoom, size, rb, off, step in cases:
+        (rays, differ, notes_differ), st = run(checker, h, eye, angle, zoom, size, rb, off, step)
+        assert rays > 0
+        assert differ == 0, (name, eye, angle, rb)
+        assert notes_differ == 0, (name, eye, angle, rb)
+        total += rays
+        for k in NAMES:
+            agg[k] = max(agg[k], st[k]) if k == "max_depth" else agg[k] + st[k]
+    p = agg["packets"]
+    print(name, f"{total} rays in {p} packets; per packet: {agg['node_visits'] / p:.1f} nodes, {agg['list_entries'] / p:.1f} list entries, "
+          f"{agg['survivors'] / p:.1f} kept by the packet test, {agg['any_pass'] / p:.1f} hit by some ray; deepest stack {agg['max_depth']}; "
+          f"per ray alone: {agg['ref_nodes'] / total:.1f} nodes, {agg['ref_tris'] / total:.1f} triangles")
+    assert total > 100000
+    # the packet test pays: it keeps a small part of the list entries
+    assert agg["survivors"] < agg["list_entries"] / 3
+
+
+def test_packet_test_off_changes_nothing(checker):
+    """The same walk with every triangle kept: the walk alone is the reference's search."""
+    h = checker.orc_scene_load(os.fsencode(scene_path("car")))
+    checker.orc_build_tree(h)
+    cam = np.zeros(7)
+    checker.orc_scene_camera(h, cam.ctypes.data)
+    (rays, differ, notes_differ), st = run(checker, h, cam[:3], cam[5], cam[6], 128, 1, 0.1, 3, cull=0)
+    assert rays > 30000 and differ == 0 and notes_differ == 0
+    assert st["survivors"] == st["list_entries"]
