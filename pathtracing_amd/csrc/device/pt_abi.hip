@@ -514,8 +514,10 @@ int ensure_workspace(PtScene *sc, int size, int batch, bool fast, int nsub, bool
     WS(ws_alloc(ws, P * nsub, &ws.B.tri));
     WS(ws_alloc(ws, P * nsub * 3, &ws.B.tuv));
     WS(ws_alloc(ws, P * nsub, &ws.B.again));
+    WS(ws_alloc(ws, P * nsub, &ws.B.again_list));
     WS(ws_alloc(ws, P * nsub, &ws.B.mirror));
     WS(ws_alloc(ws, P * nsub * 3, &ws.B.mdir));
+    WS(ws_alloc(ws, (size_t)4 * (size_t)(sc->S.n_ref > 0 ? sc->S.n_ref : 0), &ws.B.forms));
     if (fast) WS(fast_alloc(ws.Q, P, batch, shadow ? (sc->S.n_light > 1 ? sc->S.n_light : 1) : 0, ws_alloc_cb, &ws));
 #undef WS
     ws.size = size; ws.batch = batch; ws.nsub = nsub; ws.shadow = shadow;

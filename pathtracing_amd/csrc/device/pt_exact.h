@@ -344,8 +344,10 @@ struct CastHit { HitD h; D3 nrm, txt, hit, direct, alb; int reft; };
 // castRay after its search found the hit c.h: surface properties, hit point, the light loop
 // (main.cpp:51-66 for MODEL == PT_MODEL_MAIN, mainOMP.cpp:47-63 for PT_MODEL_OMP).
 // retrace_clear (mainOMP model): the search of mainOMP.cpp:60 is known to find nothing (SearchNote).
-template <int MODEL>
+// SEARCH = false (mainOMP model only): the caller vouches for retrace_clear, no search is compiled in and `st` is not used.
+template <int MODEL, bool SEARCH = true>
 PT_DEV void cast_lights(const DevScene &S, const RayD &ray, StackD &st, RayCounts &rc, CastHit &c, bool retrace_clear) {
+    static_assert(SEARCH || MODEL == PT_MODEL_OMP, "only the mainOMP model can do without its searches");
     HitD &h = c.h;
     c.nrm = surface_normal(S, h.tri, h.u, h.v);
     c.hit = dadd(dadd(ray.src, dscale(h.tmin, ray.dir)), dscale(0.0001, c.nrm));
@@ -365,8 +367,8 @@ PT_DEV void cast_lights(const DevScene &S, const RayD &ray, StackD &st, RayCount
         } else {                                             // mainOMP.cpp:60: re-traces `ray` bounded by its own hit
             // known to find nothing by the note of the first search, or because the last one found nothing and so left
             // h as it was, which makes the next one the same search
-            if (!retrace_clear) retrace_clear = !search_ref(S, ray, h, st);
-            vis = retrace_clear;
+            if (SEARCH && !retrace_clear) retrace_clear = !search_ref(S, ray, h, st);
+            vis = SEARCH ? retrace_clear : true;
             rc.n[RC_RETRACE]++;
         }
         double cosv = ddot(ldir, c.nrm);

@@ -58,11 +58,22 @@ PT_DEV RayD sub_ray(const ViewParams &V, int i, int j, int sub) {
     return camera_ray(d3(V.eye[0], V.eye[1], V.eye[2]), V.zoom, V.sa, V.ca, V.size, i, j, x, y);
 }
 
+// Before the primary search of a view: what the packet test needs of every entry of the reference lists for this
+// camera (pt_packet.h), four arrays of n_ref float4.
+__global__ void k_packet_prep(DevScene S, ViewParams V, float4 *forms) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nr = (size_t)S.n_ref;
+    if (r >= nr) return;
+    const double *tri = S.refTri + r * 9;
+    const PacketForms F = packet_forms(d3(V.ca, 0, V.sa), d3(V.sa, 0, -V.ca), d3(0, 1, 0), d3(V.eye[0], V.eye[1], V.eye[2]),
+                                       dload(tri), dload(tri + 3), dload(tri + 6));
+    forms[r] = F.det; forms[nr + r] = F.un; forms[2 * nr + r] = F.vn; forms[3 * nr + r] = F.w;
+}
+
 // Primary pass, first kernel: the search of castRay at depth 0 (main.cpp:43 / mainOMP.cpp:39) for every sub-ray, one
 // packet per wave.  Writes the hit record of each sub-ray and, for the mainOMP model, whether the second search of
 // mainOMP.cpp:60 has to be run (SearchNote); k_primary_shade does the rest of castRay from that record.
 template <int MODEL>
-__global__ void __launch_bounds__(64) k_primary_search(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B, uint32_t nblocks) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_WAVES, PT_PKT_WAVES))) k_primary_search(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B, uint32_t nblocks) {
     extern __shared__ double stack_lds[];
     const uint32_t lane = threadIdx.x & 63;
     uint32_t nprimary = 0;
@@ -76,28 +87,76 @@ __global__ void __launch_bounds__(64) k_primary_search(DevScene S, ViewParams V,
         const bool live = packet_pixel(V, blk, lane, i, j, sub) && own_row(V.part, V.n_parts, i);
         if (!__ballot(live)) continue;
         const RayD ray = sub_ray(V, i, j, sub);      // lanes that are not live get a ray too: same origin, never searched
-        const PacketBounds PB = packet_bounds(V.sa, V.ca, ray.dir, live);
+        const PacketBoundsF PB = packet_bounds_f(packet_bounds(V.sa, V.ca, ray.dir, live));
         HitD h;
         h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
         SearchNote note;
-        const bool ok = MODEL == PT_MODEL_OMP ? packet_search<true>(S, ray, live, PB, h, &note, stack_lds)
-                                              : packet_search<false>(S, ray, live, PB, h, nullptr, stack_lds);
+        const bool ok = MODEL == PT_MODEL_OMP ? packet_search<true>(S, ray, live, PB, B.forms, h, &note, stack_lds)
+                                              : packet_search<false>(S, ray, live, PB, B.forms, h, nullptr, stack_lds);
+        const bool again = MODEL == PT_MODEL_OMP && live && ok && note.may_find_closer(h.tmin);
+        if (MODEL == PT_MODEL_OMP) {                 // the few sub-rays whose second search has to be run go on a list (k_primary_again)
+            const unsigned long long am = __ballot(again);
+            if (am) {
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(am)) base = (uint32_t)atomicAdd(&F.counters[RC_AGAIN], (unsigned long long)__popcll(am));
+                base = __builtin_amdgcn_readlane(base, __builtin_ctzll(am));
+                if (again) {
+                    const size_t p = (size_t)i * V.size + j;
+                    B.again_list[base + __popcll(am & ((1ull << lane) - 1ull))] = (uint32_t)(V.rb ? p * 9 + sub : p);
+                }
+            }
+        }
         if (!live) continue;
         nprimary++;
         const size_t p = (size_t)i * V.size + j, slot = V.rb ? p * 9 + sub : p;
         B.found[slot] = ok ? 1 : 0; B.tri[slot] = ok ? h.tri : -1;
         B.tuv[3 * slot] = ok ? h.tmin : -1.0; B.tuv[3 * slot + 1] = h.u; B.tuv[3 * slot + 2] = h.v;
-        B.again[slot] = MODEL == PT_MODEL_OMP && ok && note.may_find_closer(h.tmin) ? 1 : 0;
+        B.again[slot] = again ? 1 : 0;
     }
     const uint32_t total = wave_sum(nprimary);
     if (lane == 0 && total) atomicAdd(&F.counters[RC_PRIMARY], (unsigned long long)total);
 }
 
-// Primary pass, second kernel, one thread per sub-ray: castRay at depth 0 after its search (main.cpp:44-78 /
-// mainOMP.cpp:40-78) up to its mirror bounce.  Without -rb a wave is one 8x8 pixel tile; with -rb the nine sub-rays of
-// a pixel sit in adjacent lanes (7 pixels x 9 = 63 lanes of a wave, one lane idle).  A reflective hit leaves
-// a = 0.6 txt albedo direct / pi in `paint` and its mirror ray's direction in `mdir`; k_mirror_exact adds the bounce.
-// The sub-ray results are folded into the frame buffers by k_primary_combine in the reference's order.
+// castRay at depth 0 after its search (main.cpp:44-78 / mainOMP.cpp:40-78) up to its mirror bounce, for the sub-ray in
+// `slot`, whose hit record k_primary_search wrote.  A reflective hit leaves a = 0.6 txt albedo direct / pi in `paint`
+// and its mirror ray's direction in `mdir`; k_mirror_exact adds the bounce.  The sub-ray results are folded into the
+// frame buffers by k_primary_combine in the reference's order.
+// SEARCH = false: mainOMP model, for sub-rays whose second search is known to find nothing.
+template <int MODEL, bool SEARCH>
+PT_DEV void shade_sub_ray(const DevScene &S, const ViewParams &V, const SubBuffers &B, StackD &st, RayCounts &rc, int i, int j, int sub, size_t slot) {
+    D3 paint;
+    int mirror = 0;
+    if (!B.found[slot]) {
+        const D3 zero = d3(0, 0, 0);
+        dstore(B.g + 9 * slot, zero); dstore(B.g + 9 * slot + 3, zero); dstore(B.g + 9 * slot + 6, d3(-99999, -99999, -99999));
+        paint = d3(S.bg[0], S.bg[1], S.bg[2]);
+    } else {
+        const RayD ray = sub_ray(V, i, j, sub);
+        CastHit c;
+        c.h.tri = B.tri[slot]; c.h.tmin = B.tuv[3 * slot]; c.h.u = B.tuv[3 * slot + 1]; c.h.v = B.tuv[3 * slot + 2];
+        cast_lights<MODEL, SEARCH>(S, ray, st, rc, c, MODEL == PT_MODEL_OMP && !B.again[slot]);
+        // the G-buffer candidate goes to memory as soon as it is known
+        dstore(B.g + 9 * slot, dmul(c.txt, c.alb)); dstore(B.g + 9 * slot + 3, c.nrm); dstore(B.g + 9 * slot + 6, c.hit);
+        if (MODEL == PT_MODEL_OMP && SEARCH) {       // a second search that did find something closer moved the record (mainOMP.cpp:60)
+            B.tri[slot] = c.h.tri;
+            B.tuv[3 * slot] = c.h.tmin; B.tuv[3 * slot + 1] = c.h.u; B.tuv[3 * slot + 2] = c.h.v;
+        }
+        if (c.reft) {
+            mirror = 1;
+            paint = ddivs(dmul(dmul(dscale(0.6, c.txt), c.alb), c.direct), 3.14159265358979323846);
+            dstore(B.mdir + 3 * slot, dreflect(ray.dir, c.nrm));
+            rc.n[RC_MIRROR]++;
+        } else {
+            paint = cast_value<MODEL>(c, 0, d3(0, 0, 0));
+        }
+    }
+    B.mirror[slot] = mirror;
+    dstore(B.paint + 3 * slot, paint);
+}
+
+// Primary pass, second kernel of the main.cpp model, one thread per sub-ray: the shadow rays are searches, so the
+// kernel runs as resident one-wave blocks with a stack each.  Without -rb a wave is one 8x8 pixel tile; with -rb the
+// nine sub-rays of a pixel sit in adjacent lanes (7 pixels x 9 = 63 lanes of a wave, one lane idle).
 template <int MODEL>
 __global__ void __launch_bounds__(64) k_primary_shade(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B, uint32_t nblocks) {
     extern __shared__ double stack_lds[];
@@ -125,35 +184,52 @@ __global__ void __launch_bounds__(64) k_primary_shade(DevScene S, ViewParams V, 
         int i = 0, j = 0;
         live = live && tile_pixel((int)lin, V.size, i, j) && own_row(V.part, V.n_parts, i);
         if (!live) continue;
-        const size_t p = (size_t)i * V.size + j, slot = V.rb ? p * 9 + sub : p;
-        D3 paint;
-        int mirror = 0;
-        if (!B.found[slot]) {
-            const D3 zero = d3(0, 0, 0);
-            dstore(B.g + 9 * slot, zero); dstore(B.g + 9 * slot + 3, zero); dstore(B.g + 9 * slot + 6, d3(-99999, -99999, -99999));
-            paint = d3(S.bg[0], S.bg[1], S.bg[2]);
-        } else {
-            const RayD ray = sub_ray(V, i, j, sub);
-            CastHit c;
-            c.h.tri = B.tri[slot]; c.h.tmin = B.tuv[3 * slot]; c.h.u = B.tuv[3 * slot + 1]; c.h.v = B.tuv[3 * slot + 2];
-            cast_lights<MODEL>(S, ray, st, rc, c, MODEL == PT_MODEL_OMP && !B.again[slot]);
-            // the G-buffer candidate goes to memory as soon as it is known
-            dstore(B.g + 9 * slot, dmul(c.txt, c.alb)); dstore(B.g + 9 * slot + 3, c.nrm); dstore(B.g + 9 * slot + 6, c.hit);
-            if (MODEL == PT_MODEL_OMP) {             // a second search that did find something closer moved the record (mainOMP.cpp:60)
-                B.tri[slot] = c.h.tri;
-                B.tuv[3 * slot] = c.h.tmin; B.tuv[3 * slot + 1] = c.h.u; B.tuv[3 * slot + 2] = c.h.v;
-            }
-            if (c.reft) {
-                mirror = 1;
-                paint = ddivs(dmul(dmul(dscale(0.6, c.txt), c.alb), c.direct), 3.14159265358979323846);
-                dstore(B.mdir + 3 * slot, dreflect(ray.dir, c.nrm));
-                rc.n[RC_MIRROR]++;
-            } else {
-                paint = cast_value<MODEL>(c, 0, d3(0, 0, 0));
-            }
+        const size_t p = (size_t)i * V.size + j;
+        shade_sub_ray<MODEL, true>(S, V, B, st, rc, i, j, sub, V.rb ? p * 9 + sub : p);
+    }
+    flush_counts(rc, F.counters);
+}
+
+// The same for the mainOMP model, whose light loop searches nothing new: the second search of mainOMP.cpp:60 is known
+// to find nothing for all but the few sub-rays on the list (SearchNote), so this kernel has no search, no stack, and
+// runs at full occupancy, one thread per sub-ray in memory order; k_primary_again does the listed ones.
+__global__ void __launch_bounds__(256) k_primary_shade_omp(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B) {
+    RayCounts rc;
+#pragma unroll
+    for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
+    const size_t nsub = V.rb ? 9 : 1, total = (size_t)V.size * V.size * nsub;
+    for (size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = slot / nsub;
+        const int i = (int)(p / (size_t)V.size), j = (int)(p - (size_t)i * V.size);
+        if (own_row(V.part, V.n_parts, i) && !B.again[slot]) {
+            StackD none;
+            shade_sub_ray<PT_MODEL_OMP, false>(S, V, B, none, rc, i, j, V.rb ? (int)(slot - p * nsub) : 4, slot);
         }
-        B.mirror[slot] = mirror;
-        dstore(B.paint + 3 * slot, paint);
+    }
+    // one update of the view's counters per block: updates of one word run at some 90 per microsecond on the whole chip,
+    // so one per wave of a launch of 37 000 waves would take longer than the shading
+    __shared__ uint32_t sums[RC_WORK_PRIMARY];
+    if (threadIdx.x < RC_WORK_PRIMARY) sums[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RC_WORK_PRIMARY; k++) {
+        const uint32_t w = wave_sum(rc.n[k]);
+        if ((threadIdx.x & 63) == 0 && w) atomicAdd(&sums[k], w);
+    }
+    __syncthreads();
+    if (threadIdx.x < RC_WORK_PRIMARY && sums[threadIdx.x]) atomicAdd(&F.counters[threadIdx.x], (unsigned long long)sums[threadIdx.x]);
+}
+__global__ void __launch_bounds__(64) k_primary_again(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B) {
+    extern __shared__ double stack_lds[];
+    StackD st = make_stack(S, stack_lds);
+    RayCounts rc;
+#pragma unroll
+    for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
+    const size_t n = (size_t)F.counters[RC_AGAIN], nsub = V.rb ? 9 : 1;
+    for (size_t k = (size_t)blockIdx.x * 64 + threadIdx.x; k < n; k += (size_t)gridDim.x * 64) {
+        const size_t slot = B.again_list[k], p = slot / nsub;
+        const int i = (int)(p / (size_t)V.size), j = (int)(p - (size_t)i * V.size);
+        shade_sub_ray<PT_MODEL_OMP, true>(S, V, B, st, rc, i, j, V.rb ? (int)(slot - p * nsub) : 4, slot);
     }
     flush_counts(rc, F.counters);
 }
@@ -358,6 +434,7 @@ int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F,
     const unsigned cblocks = (unsigned)((P + 255) / 256);
     const unsigned blocks = V.rb ? (unsigned)(((size_t)tile_threads(V.size) * 9 + 62) / 63) : (unsigned)(tile_threads(V.size) / 64);
     const unsigned pblocks = packet_blocks(V.size, V.rb);
+    if (S.n_ref > 0) hipLaunchKernelGGL(k_packet_prep, dim3(((unsigned)S.n_ref + 255u) / 256u), dim3(256), 0, s, S, V, B.forms);
     if (V.model == PT_MODEL_MAIN) {
         static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_MAIN>, PT_EXACT_WAVES), wp = resident_waves(k_primary_shade<PT_MODEL_MAIN>, PT_EXACT_WAVES),
                               wm = resident_waves(k_mirror_exact<PT_MODEL_MAIN>, PT_EXACT_WAVES);
@@ -366,10 +443,13 @@ int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F,
         if (S.any_mirror) hipLaunchKernelGGL(k_mirror_exact<PT_MODEL_MAIN>, dim3(blocks < wm ? blocks : wm), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         hipLaunchKernelGGL(k_primary_combine<PT_MODEL_MAIN>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb, V.part, V.n_parts);
     } else {
-        static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_OMP>, PT_EXACT_WAVES), wp = resident_waves(k_primary_shade<PT_MODEL_OMP>, PT_EXACT_WAVES),
-                              wm = resident_waves(k_mirror_exact<PT_MODEL_OMP>, PT_EXACT_WAVES);
+        static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_OMP>, PT_EXACT_WAVES), wm = resident_waves(k_mirror_exact<PT_MODEL_OMP>, PT_EXACT_WAVES);
+        const size_t slots = P * (V.rb ? 9 : 1);
         hipLaunchKernelGGL(k_primary_search<PT_MODEL_OMP>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, pblocks);
-        hipLaunchKernelGGL(k_primary_shade<PT_MODEL_OMP>, dim3(blocks < wp ? blocks : wp), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
+        const size_t sblocks = (slots + 255) / 256;
+        hipLaunchKernelGGL(k_primary_shade_omp, dim3((unsigned)(sblocks < 2048 ? sblocks : 2048)), dim3(256), 0, s, S, V, F, B);
+        // the listed sub-rays: few, so a grid of one wave per SIMD-quarter of the chip is plenty (the list's length is on the device)
+        hipLaunchKernelGGL(k_primary_again, dim3(256), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B);
         if (S.any_mirror) hipLaunchKernelGGL(k_mirror_exact<PT_MODEL_OMP>, dim3(blocks < wm ? blocks : wm), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         hipLaunchKernelGGL(k_primary_combine<PT_MODEL_OMP>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb, V.part, V.n_parts);
     }

@@ -47,6 +47,8 @@ struct SubBuffers {
     int32_t *again;            // mainOMP model: the second search of mainOMP.cpp:60 has to be run for this sub-ray
     int32_t *mirror;           // the hit is reflective: `paint` holds the hit's own term until the bounce is added
     double *mdir;              // 3: direction of the mirror ray (its origin is the hit point in `g`)
+    uint32_t *again_list;      // the sub-rays with `again` set, in no particular order (counters[RC_AGAIN] of them)
+    float4 *forms;             // per view, not per sub-ray: the packet test's table, 4 arrays of n_ref entries (pt_packet.h)
 };
 
 // Queues and slots of the fp32 GI wavefront path (pt_fast.hip).

@@ -7,12 +7,22 @@
 // rays advance changes.  tests/packet_check.c states the same walk in plain C and checks it against the oracle.
 //
 // Before the rays test the triangles of a node, the packet as a whole is tested against them, one triangle per lane
-// (packet_cull): a triangle that provably none of the packet's rays can pass is left out.
+// (packet_cull): a triangle that provably none of the packet's rays can pass is left out.  What that test needs of a
+// triangle depends on the camera only, and is written once per view for every entry of the reference lists (k_packet_prep).
 #pragma once
 #include "pt_exact.h"
 
 #define PT_PKT_LDS 8                       // stack entries whose per-lane numbers live in LDS; deeper ones in device memory
-#define PT_PKT_CULL_MIN 3                  // lists shorter than this are tested without the packet test
+#define PT_PKT_CULL_MIN 1                  // lists shorter than this are tested without the packet test
+#ifndef PT_PKT_PRE_TRI
+#define PT_PKT_PRE_TRI 0                   // the next triangle of a list is fetched while the current one is tested
+#endif
+#ifndef PT_PKT_PRE_NODE
+#define PT_PKT_PRE_NODE 0                  // both children of a node are fetched before its list is gone through
+#endif
+#ifndef PT_PKT_WAVES
+#define PT_PKT_WAVES 4                     // waves per SIMD the search kernel is compiled for
+#endif
 
 PT_DEV double wave_min_d(double v) {
 #pragma unroll
@@ -50,17 +60,10 @@ PT_DEV PacketBounds packet_bounds(double sa, double ca, const D3 &dir, bool live
 }
 
 PT_DEV double dl1(const D3 &a) { return fabs(a.x) + fabs(a.y) + fabs(a.z); }
-// Range of the linear form d . A over the packet's directions.
-PT_DEV void form_range(const PacketBounds &B, const D3 &A, double &lo, double &hi) {
-    const double f0 = ddot(B.Z, A), fa = ddot(B.X, A), fb = ddot(B.Y, A);
-    const double x0 = B.c0 * f0, x1 = B.c1 * f0, y0 = B.a0 * fa, y1 = B.a1 * fa, z0 = B.b0 * fb, z1 = B.b1 * fb;
-    const double r = B.rr * dl1(A);
-    lo = fmin(x0, x1) + fmin(y0, y1) + fmin(z0, z1) - r;
-    hi = fmax(x0, x1) + fmax(y0, y1) + fmax(z0, z1) + r;
-}
 
-// true: no ray that leaves `o` with a direction inside B can pass the reference's tests on the triangle (v0, e1, e2),
-// so the reference rejects it for every ray of the packet and leaving it out changes nothing.
+// The packet test: true means that no ray that leaves `o` with a direction inside the packet's bounds can pass the
+// reference's tests on the triangle (v0, e1, e2), so the reference rejects it for every ray of the packet and leaving
+// it out changes nothing.
 //
 // With T = o - v0 the reference computes, per ray of direction d (util/polygonMesh.cpp:56-72),
 //     det = (d x e2) . e1 = d . (e2 x e1)      u = un / det,  un = (d x e2) . T  = d . (e2 x T)
@@ -70,29 +73,66 @@ PT_DEV void form_range(const PacketBounds &B, const D3 &A, double &lo, double &h
 // depend on d.  The triangle is left out when the sign of det is the same for the whole packet and, with that sign,
 // un < 0, or vn < 0, or w > 0, or tn < 0 holds for the whole packet -- each by a margin:
 // every quantity is a sum of at most six products x_i y_j z_k of three vectors, so M = |x|_1 |y|_1 |z|_1 bounds the sum of
-// their magnitudes, and any fp64 evaluation of it (the reference's, this one's, the range arithmetic on top) is within
-// 40 * 2^-53 * M < 1e-14 M of the exact value.  The margins are 1e-12 M, and M is required to lie in [1e-100, 1e100], so a
-// quantity that clears its margin has the claimed sign as the reference computes it, and the quotients the reference
-// forms from such quantities are at least 1e-12 in magnitude away from 0 (resp. from 1 for u + v): no rounding, underflow or
-// NaN can turn the comparison.  Triangles outside that range of magnitudes, and packets for which det changes sign, are kept.
-PT_DEV bool packet_cull(const PacketBounds &B, const D3 &o, const D3 &v0, const D3 &e1, const D3 &e2) {
-    const double K = 1e-12;
+// their magnitudes, and any fp64 evaluation of it (the reference's, this one's) is within 40 * 2^-53 * M < 1e-14 M of the
+// exact value.  A quantity that is at least 1e-12 M away from zero therefore has its sign as the reference computes it,
+// and the quotients the reference forms from such quantities are at least 1e-12 in magnitude away from 0 (resp. from 1
+// for u + v): no rounding, underflow or NaN can turn the comparison.  M is required to lie in [1e-100, 1e100];
+// triangles outside that range of magnitudes, and packets for which det changes sign, are kept.
+//
+// All camera rays of a view leave the same point, so everything but the packet's bounds is a property of the (view,
+// reference) pair: k_packet_prep writes, once per view and reference, the four linear forms in the camera's frame, each
+// divided by its M (so that the margin is a constant and nothing can overflow), rounded to fp32, and the sign class of
+// tn.  The packet then evaluates the forms' ranges in fp32: 3 multiplications by bounds of magnitude <= 1.5, a min / max
+// and two additions per end, on inputs rounded once -- within 23 * 2^-24 < 1.4e-6 of the fp64 value, to which the
+// remainder term of the bounds adds less than 1e-7 (checked per packet) -- and asks for a margin of 1e-5 where fp64
+// needs 1e-12.  What it gives up is triangles that miss the packet by less than 1e-5 of their own size.
+#define PT_PKT_MARGIN 1e-5f
+struct PacketForms { float4 det, un, vn, w; };      // xyz: the form on the camera's Z, X, Y; det.w: sign class of tn (+1, -1, 0)
+
+PT_DEV PacketForms packet_forms(const D3 &Z, const D3 &X, const D3 &Y, const D3 &o, const D3 &v0, const D3 &e1, const D3 &e2) {
     const D3 T = dsub(o, v0);
     const D3 Nn = dcross(e2, e1), A = dcross(e2, T), Bv = dcross(T, e1);
     const D3 Cw = dsub(dadd(A, Bv), Nn);
     const double tn = ddot(Bv, e2);
     const double n1 = dl1(e1), n2 = dl1(e2), nT = dl1(T);
-    const double Md = 2.0 * n1 * n2, Mu = 2.0 * n2 * nT, Mv = 2.0 * nT * n1, Mt = nT * n1 * n2;
-    if (!(Md >= 1e-100 && Md <= 1e100 && Mu >= 1e-100 && Mu <= 1e100 && Mv >= 1e-100 && Mv <= 1e100 && Mt <= 1e100)) return false;
-    const double md = K * Md, mu = K * Mu, mv = K * Mv, mw = K * (Md + Mu + Mv), mt = K * Mt;
-    double dlo, dhi, ulo, uhi, vlo, vhi, wlo, whi;
-    form_range(B, Nn, dlo, dhi);
-    const bool pos = dlo > md, neg = dhi < -md;
-    form_range(B, A, ulo, uhi);
-    form_range(B, Bv, vlo, vhi);
-    form_range(B, Cw, wlo, whi);
-    const bool out_pos = uhi < -mu || vhi < -mv || wlo > mw || tn < -mt;
-    const bool out_neg = ulo > mu || vlo > mv || whi < -mw || tn > mt;
+    const double Md = 2.0 * n1 * n2, Mu = 2.0 * n2 * nT, Mv = 2.0 * nT * n1, Mt = nT * n1 * n2, Mw = Md + Mu + Mv;
+    PacketForms F;
+    const float nan = __int_as_float(0x7FC00000);
+    if (!(Md >= 1e-100 && Md <= 1e100 && Mu >= 1e-100 && Mu <= 1e100 && Mv >= 1e-100 && Mv <= 1e100 && Mt <= 1e100)) {
+        F.det = F.un = F.vn = F.w = make_float4(nan, nan, nan, 0.f);      // every comparison fails: kept
+        return F;
+    }
+    const double mt = 1e-12 * Mt;
+    F.det = make_float4((float)(ddot(Nn, Z) / Md), (float)(ddot(Nn, X) / Md), (float)(ddot(Nn, Y) / Md), tn > mt ? 1.f : (tn < -mt ? -1.f : 0.f));
+    F.un = make_float4((float)(ddot(A, Z) / Mu), (float)(ddot(A, X) / Mu), (float)(ddot(A, Y) / Mu), 0.f);
+    F.vn = make_float4((float)(ddot(Bv, Z) / Mv), (float)(ddot(Bv, X) / Mv), (float)(ddot(Bv, Y) / Mv), 0.f);
+    F.w = make_float4((float)(ddot(Cw, Z) / Mw), (float)(ddot(Cw, X) / Mw), (float)(ddot(Cw, Y) / Mw), 0.f);
+    return F;
+}
+
+// The packet's bounds as the fp32 test reads them; ok: the remainder term is small enough to be covered by the margin.
+struct PacketBoundsF { float c0, c1, a0, a1, b0, b1; bool ok; };
+PT_DEV PacketBoundsF packet_bounds_f(const PacketBounds &B) {
+    PacketBoundsF b;
+    b.c0 = (float)B.c0; b.c1 = (float)B.c1; b.a0 = (float)B.a0; b.a1 = (float)B.a1; b.b0 = (float)B.b0; b.b1 = (float)B.b1;
+    b.ok = B.rr < 1e-7 && fabs(B.c0) <= 1.5 && fabs(B.c1) <= 1.5 && fabs(B.a0) <= 1.5 && fabs(B.a1) <= 1.5 && fabs(B.b0) <= 1.5 && fabs(B.b1) <= 1.5;
+    return b;
+}
+PT_DEV void form_range_f(const PacketBoundsF &b, const float4 &f, float &lo, float &hi) {
+    const float x0 = b.c0 * f.x, x1 = b.c1 * f.x, y0 = b.a0 * f.y, y1 = b.a1 * f.y, z0 = b.b0 * f.z, z1 = b.b1 * f.z;
+    lo = fminf(x0, x1) + fminf(y0, y1) + fminf(z0, z1);
+    hi = fmaxf(x0, x1) + fmaxf(y0, y1) + fmaxf(z0, z1);
+}
+PT_DEV bool packet_cull(const PacketBoundsF &b, const float4 &fd, const float4 &fu, const float4 &fv, const float4 &fw) {
+    const float K = PT_PKT_MARGIN;
+    float dlo, dhi, ulo, uhi, vlo, vhi, wlo, whi;
+    form_range_f(b, fd, dlo, dhi);
+    form_range_f(b, fu, ulo, uhi);
+    form_range_f(b, fv, vlo, vhi);
+    form_range_f(b, fw, wlo, whi);
+    const bool pos = dlo > K, neg = dhi < -K;
+    const bool out_pos = uhi < -K || vhi < -K || wlo > K || fd.w < 0.f;
+    const bool out_neg = ulo > K || vlo > K || whi < -K || fd.w > 0.f;
     return (pos && out_pos) || (neg && out_neg);
 }
 
@@ -143,38 +183,86 @@ PT_DEV PacketStack make_packet_stack(const DevScene &S, double *lds) {
     return st;
 }
 
+// A triangle of a reference list and a node of the tree, fetched through the scalar unit (the whole wave wants the same one).
+struct TriU { D3 v0, e1, e2; int32_t id; };
+PT_DEV TriU load_tri_u(const DevScene &S, int k) {
+    const double *tri = S.refTri + (size_t)k * 9;
+    TriU t;
+    t.v0 = uload3(tri); t.e1 = uload3(tri + 3); t.e2 = uload3(tri + 6);
+    t.id = ((PtUniformI)(uintptr_t)S.refId)[k];
+    return t;
+}
+PT_DEV NodeA load_node_u(const DevScene &S, int k) {
+    typedef const NodeA __attribute__((address_space(4))) *PtUniformNode;
+    const PtUniformNode q = (PtUniformNode)(uintptr_t)S.nodeA + k;
+    NodeA n;
+    n.split = q->split; n.axis = q->axis; n.left = q->left; n.first = q->first; n.count = q->count;
+    return n;
+}
+
+// The rays of a packet as the walk reads them: the origin (one for the whole wave), the direction, and per axis the
+// divisor of util/kdtree.cpp:236 -- all plain values, so that picking a component by the node's axis is a select
+// between registers.
+struct PacketRay { double ox, oy, oz, dx, dy, dz, tx, ty, tz; };
+PT_DEV PacketRay packet_ray(const RayD &r) {
+    PacketRay p;
+    p.ox = uniform_d(r.src.x); p.oy = uniform_d(r.src.y); p.oz = uniform_d(r.src.z);
+    p.dx = r.dir.x; p.dy = r.dir.y; p.dz = r.dir.z;
+    p.tx = p.dx == 0 ? 0.0000001 : p.dx; p.ty = p.dy == 0 ? 0.0000001 : p.dy; p.tz = p.dz == 0 ? 0.0000001 : p.dz;
+    return p;
+}
+
 // KDNode::searchNode (util/kdtree.cpp:180-197) for the rays `in` of the packet on the list of node `node0`.
-PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, const RayD &ray, bool in, const PacketBounds &B, HitD &h) {
+// forms: the view's table of k_packet_prep, four arrays of n_ref entries (det, un, vn, w).
+PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, const RayD &ray, bool in, const PacketBoundsF &B,
+                        const float4 *forms, HitD &h) {
     const uint32_t lane = threadIdx.x & 63u;
     bool improved = false;
     for (int base = 0; base < count0; base += 64) {
         const int n = count0 - base < 64 ? count0 - base : 64;
         unsigned long long surv = n == 64 ? ~0ull : (1ull << n) - 1ull;
-        if (count0 >= PT_PKT_CULL_MIN) {
+        if (B.ok && count0 >= PT_PKT_CULL_MIN) {
             bool keep = false;
             if ((int)lane < n) {
-                const double *tri = S.refTri + (size_t)(first0 + base + (int)lane) * 9;
-                keep = !packet_cull(B, ray.src, dload(tri), dload(tri + 3), dload(tri + 6));
+                const float4 *f = forms + (size_t)(first0 + base + (int)lane);
+                const size_t nr = (size_t)S.n_ref;
+                keep = !packet_cull(B, f[0], f[nr], f[2 * nr], f[3 * nr]);
             }
             surv = __ballot(keep);
         }
-        while (surv) {
-            const int k = first0 + base + (int)__builtin_ctzll(surv);
-            surv &= surv - 1ull;
+        if (!surv) continue;
+        // the triangles that are left, one after the other for the whole wave; the next one is on its way while this one is tested
+        int k = first0 + base + (int)__builtin_ctzll(surv);
+        surv &= surv - 1ull;
+        TriU cur = load_tri_u(S, k);
+        for (;;) {
+            const bool more = surv != 0;
+            TriU nxt = cur;
+            if (PT_PKT_PRE_TRI && more) {
+                k = first0 + base + (int)__builtin_ctzll(surv);
+                surv &= surv - 1ull;
+                nxt = load_tri_u(S, k);
+            }
             if (in) {
-                const double *tri = S.refTri + (size_t)k * 9;
                 double t, bu, bv;
-                if (tri_intersect(uload3(tri), uload3(tri + 3), uload3(tri + 6), ray, t, bu, bv) && t > 0 && t < h.tmin) {
+                if (tri_intersect(cur.v0, cur.e1, cur.e2, ray, t, bu, bv) && t > 0 && t < h.tmin) {
                     const D3 hit = dadd(ray.src, dscale(t, ray.dir));
                     const double *b = S.nodeBox + (size_t)node0 * 6;
                     const D3 lo = uload3(b), hi = uload3(b + 3);
                     if (hit.x >= lo.x && hit.y >= lo.y && hit.z >= lo.z && hit.x <= hi.x && hit.y <= hi.y && hit.z <= hi.z) {
                         improved = true;
                         h.tmin = t; h.u = bu; h.v = bv;
-                        h.tri = ((PtUniformI)(uintptr_t)S.refId)[k];
+                        h.tri = cur.id;
                     }
                 }
             }
+            if (!more) break;
+            if (!PT_PKT_PRE_TRI) {
+                k = first0 + base + (int)__builtin_ctzll(surv);
+                surv &= surv - 1ull;
+                nxt = load_tri_u(S, k);
+            }
+            cur = nxt;
         }
     }
     return improved;
@@ -183,8 +271,10 @@ PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, co
 // The search of every `live` ray of the wave: src (the same for all) and `dir`; h.tmin is the in/out bound as in
 // search_ref_t, whose result and notes this returns.  Every lane of the wave must call it.
 template <bool NOTED>
-PT_DEV bool packet_search(const DevScene &S, const RayD &ray, bool live, const PacketBounds &B, HitD &h, SearchNote *note, double *lds) {
+PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, const PacketBoundsF &B, const float4 *forms, HitD &h, SearchNote *note, double *lds) {
     const uint32_t lane = threadIdx.x & 63u;
+    const PacketRay pr = packet_ray(ray_in);
+    const RayD ray = make_ray(d3(pr.ox, pr.oy, pr.oz), d3(pr.dx, pr.dy, pr.dz));
     PacketStack st = make_packet_stack(S, lds);
     double ent = 0, ext = 0;
     if (NOTED) { note->far_max = -DBL_MAX; note->stack_min = DBL_MAX; }
@@ -193,6 +283,7 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray, bool live, const P
     bool found = false, at_leaf = false;
     unsigned long long act = __ballot(in);
     int curr = 0;
+    NodeA nd = load_node_u(S, 0);
     for (;;) {
         if (!act) {
             if (!NOTED && !__ballot(!finished)) break;
@@ -210,29 +301,30 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray, bool live, const P
                 act = __ballot(in);
             }
             if (!act) break;
+            nd = load_node_u(S, curr);
         }
-        typedef const NodeA __attribute__((address_space(4))) *PtUniformNode;
-        const PtUniformNode q = (PtUniformNode)(uintptr_t)S.nodeA + curr;
-        const double split = q->split;
-        const int axis = q->axis, left = q->left, first = q->first, count = q->count;
+        const double split = nd.split;
+        const int axis = nd.axis, left = nd.left;
+        // both children are asked for before this node's list is gone through: one of them is the next node
+        NodeA c0 = nd, c1 = nd;
+        if (PT_PKT_PRE_NODE && axis >= 0) { c0 = load_node_u(S, left); c1 = load_node_u(S, left + 1); }
         bool improved = false;
-        if (count > 0) improved = packet_node(S, curr, first, count, ray, in, B, h);
+        if (nd.count > 0) improved = packet_node(S, curr, nd.first, nd.count, ray, in, B, forms, h);
         if (axis < 0) {                              // a leaf: the rays that improved their hit here are done (:252-253)
             if (in && improved) { at_leaf = true; finished = true; }
             act = 0;
             continue;
         }
         found |= in && improved;
-        const double da = axis == 0 ? ray.dir.x : (axis == 1 ? ray.dir.y : ray.dir.z);
-        const double sa = axis == 0 ? ray.src.x : (axis == 1 ? ray.src.y : ray.src.z);
-        const double tdir = da == 0 ? 0.0000001 : da;
+        const double sa = axis == 0 ? pr.ox : (axis == 1 ? pr.oy : pr.oz);
+        const double tdir = axis == 0 ? pr.tx : (axis == 1 ? pr.ty : pr.tz);
         const double tmid = (split - sa) / tdir;
         const bool near_only = tmid >= ext || tmid < 0;
         const bool far_only = !near_only && tmid <= ent && tmid <= h.tmin;
         const bool push = !near_only && !far_only && tmid <= h.tmin;
         const unsigned long long nearm = __ballot(in && !far_only), farm = __ballot(in && far_only), pushm = __ballot(in && push);
         if (NOTED && in && far_only && tmid > note->far_max) note->far_max = tmid;
-        const bool swap = __builtin_amdgcn_readfirstlane((int)(sa > split)) != 0;     // the same for every ray: they share src
+        const bool swap = sa > split;                // the same for every ray: they share src
         const int nr = swap ? left + 1 : left, fr = swap ? left : left + 1;
         if (nearm) {
             if (farm | pushm) {
@@ -245,9 +337,12 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray, bool live, const P
             if (in && !near_only && !far_only) ext = tmid;
             in = in && !far_only;
             curr = nr; act = nearm;
+            nd = swap ? c1 : c0;
         } else {
             curr = fr; act = farm;
+            nd = swap ? c0 : c1;
         }
+        if (!PT_PKT_PRE_NODE) nd = load_node_u(S, curr);
     }
     return at_leaf || found;
 }

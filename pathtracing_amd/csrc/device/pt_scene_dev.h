@@ -73,7 +73,6 @@ struct DevScene {
     double root_lo[3], root_hi[3];
 };
 
-// ray counters of a view, then the work counters the persistent primary / mirror kernels draw their blocks from
 // The immutable arrays of a DevScene live in ONE device allocation (the scene slab); these are the pointer fields that
 // point into it.  A slab is position independent: its header holds a DevScene whose pointer fields are byte offsets
 // from the slab's start, so a copy of the slab on another GPU (or in another process) becomes a scene by adding its
@@ -83,4 +82,6 @@ struct DevScene {
     X(tri_mesh) X(tri_local) X(norm) X(uv) X(albedo) X(triShadeF) X(texels) X(tex_off) X(tex_rows) X(tex_cols) X(lights) X(lightsF)
 
 enum { PT_LIMIT_F32_STACK = 1, PT_LIMIT_F32_STEPS = 2, PT_LIMIT_F64_STACK = 4 };
-enum { RC_PRIMARY = 0, RC_SHADOW = 1, RC_MIRROR = 2, RC_GI = 3, RC_RETRACE = 4, RC_WORK_PRIMARY = 5, RC_WORK_MIRROR = 6, RC_LIMITS = 7, RC_WORK_SHADE = 8, RC_N = 9 };
+// ray counters of a view, the work counters the persistent primary / mirror / shading kernels draw their blocks from, the limit
+// word, and the length of the list of sub-rays whose second search (mainOMP.cpp:60) has to be run
+enum { RC_PRIMARY = 0, RC_SHADOW = 1, RC_MIRROR = 2, RC_GI = 3, RC_RETRACE = 4, RC_WORK_PRIMARY = 5, RC_WORK_MIRROR = 6, RC_LIMITS = 7, RC_WORK_SHADE = 8, RC_AGAIN = 9, RC_N = 10 };

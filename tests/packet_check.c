@@ -9,7 +9,10 @@
  * test the triangles of a node, the packet as a whole is tested against them (one triangle per lane): a triangle that
  * provably none of the packet's rays can hit is left out.  This file states both parts in plain C:
  *     packet_search()   the walk, with the notes the device keeps for mainOMP.cpp:60 (see research_check.c)
- *     packet_cull()     the conservative packet-vs-triangle test
+ *     packet_cull()     the conservative packet-vs-triangle test as the proof is written: fp64, margin 1e-12
+ *     packet_cull_f()   the test the device runs: the same linear forms per (camera, triangle), divided by their
+ *                       magnitude bounds and rounded to fp32, ranges evaluated in fp32, margin 1e-5; every triangle
+ *                       it leaves out must also be left out by packet_cull() (counted in `loose`, which must be 0)
  * and packet_check() runs them on the camera rays of a view, packets formed as the device forms them, and counts every
  * ray whose result differs from search_ref()/search_noted() in any bit.
  */
@@ -22,7 +25,7 @@ typedef unsigned long long u64;
 
 typedef struct {
     long packets, rays, node_visits, lists, list_entries, survivors, lane_tests, any_pass, pushes, pops, max_depth;
-    long ref_node_visits, ref_tri_tests;
+    long ref_node_visits, ref_tri_tests, loose, kept64;
     long depth_hist[64];
 } PStats;
 
@@ -81,6 +84,50 @@ static int packet_cull(const Bundle *B, V3 o, V3 v0, V3 e1, V3 e2) {
     return ulo > mu || vlo > mv || whi < -mw || tn > mt;
 }
 
+/* The device's form of the test (pt_packet.h: packet_forms, packet_bounds_f, packet_cull). */
+typedef struct { float f[4][3]; float tsign; } Forms;
+static Forms packet_forms(const Bundle *B, V3 o, V3 v0, V3 e1, V3 e2) {
+    Forms F; memset(&F, 0, sizeof F);
+    V3 T = vsub(o, v0);
+    V3 Nn = vcross(e2, e1), A = vcross(e2, T), Bv = vcross(T, e1);
+    V3 Cw = vsub(vadd(A, Bv), Nn);
+    double tn = vdot(Bv, e2);
+    double n1 = l1(e1), n2 = l1(e2), nT = l1(T);
+    double Md = 2.0 * n1 * n2, Mu = 2.0 * n2 * nT, Mv = 2.0 * nT * n1, Mt = nT * n1 * n2, Mw = Md + Mu + Mv;
+    if (!(Md >= 1e-100 && Md <= 1e100 && Mu >= 1e-100 && Mu <= 1e100 && Mv >= 1e-100 && Mv <= 1e100 && Mt <= 1e100)) {
+        for (int k = 0; k < 4; k++) for (int c = 0; c < 3; c++) F.f[k][c] = NAN;
+        return F;
+    }
+    double mt = 1e-12 * Mt;
+    const V3 form[4] = { Nn, A, Bv, Cw };
+    const double M[4] = { Md, Mu, Mv, Mw };
+    for (int k = 0; k < 4; k++) {
+        F.f[k][0] = (float)(vdot(form[k], B->d0) / M[k]);
+        F.f[k][1] = (float)(vdot(form[k], B->a) / M[k]);
+        F.f[k][2] = (float)(vdot(form[k], B->b) / M[k]);
+    }
+    F.tsign = tn > mt ? 1.f : (tn < -mt ? -1.f : 0.f);
+    return F;
+}
+static inline void form_range_f(const float b[6], const float f[3], float *lo, float *hi) {
+    float x0 = b[0] * f[0], x1 = b[1] * f[0], y0 = b[2] * f[1], y1 = b[3] * f[1], z0 = b[4] * f[2], z1 = b[5] * f[2];
+    *lo = fminf(x0, x1) + fminf(y0, y1) + fminf(z0, z1);
+    *hi = fmaxf(x0, x1) + fmaxf(y0, y1) + fmaxf(z0, z1);
+}
+static int packet_cull_f(const Bundle *B, const Forms *F) {
+    const float K = 1e-5f;
+    const float b[6] = { (float)B->c0, (float)B->c1, (float)B->a0, (float)B->a1, (float)B->b0, (float)B->b1 };
+    if (!(B->rr < 1e-7 && fabs(B->c0) <= 1.5 && fabs(B->c1) <= 1.5 && fabs(B->a0) <= 1.5 && fabs(B->a1) <= 1.5 &&
+          fabs(B->b0) <= 1.5 && fabs(B->b1) <= 1.5))
+        return 0;
+    float lo[4], hi[4];
+    for (int k = 0; k < 4; k++) form_range_f(b, F->f[k], &lo[k], &hi[k]);
+    int pos = lo[0] > K, neg = hi[0] < -K;
+    int out_pos = hi[1] < -K || hi[2] < -K || lo[3] > K || F->tsign < 0.f;
+    int out_neg = lo[1] > K || lo[2] > K || hi[3] < -K || F->tsign > 0.f;
+    return (pos && out_pos) || (neg && out_neg);
+}
+
 typedef struct { const KD *node; u64 push, defer; double ent[PW], ext[PW]; } PEntry;
 
 /* One node's list for the rays in `act`; returns the mask of rays that improved their hit here. */
@@ -92,8 +139,14 @@ static u64 packet_node(const Scene *s, const KD *nd, const Ray *rays, u64 act, c
         ps->list_entries++;
         if (cull) {
             const int *V = me->tris[nd->t[i]].vi;
-            V3 v0 = me->vert[V[0]];
-            if (packet_cull(B, rays[__builtin_ctzll(act)].src, v0, vsub(me->vert[V[1]], v0), vsub(me->vert[V[2]], v0))) continue;
+            V3 v0 = me->vert[V[0]], e1 = vsub(me->vert[V[1]], v0), e2 = vsub(me->vert[V[2]], v0), o = rays[__builtin_ctzll(act)].src;
+            const int out64 = packet_cull(B, o, v0, e1, e2);
+            if (!out64) ps->kept64++;
+            const Forms F = packet_forms(B, o, v0, e1, e2);
+            if (packet_cull_f(B, &F)) {
+                if (!out64) ps->loose++;               /* the fp32 test claimed more than the fp64 test proves */
+                continue;
+            }
         }
         ps->survivors++;
         int any = 0;

@@ -1,7 +1,10 @@
 """The packet search of the primary pass (pathtracing_amd/csrc/device/pt_packet.h), checked on the CPU: tests/packet_check.c
 states the walk and the packet-vs-triangle test in plain C and compares every camera ray's result and notes with the
 oracle's own search, bit for bit.  A triangle that the packet test leaves out although some ray of the packet hits it
-would show up as a differing ray, so `differ == 0` is also the statement that the test never rejects wrongly."""
+would show up as a differing ray, so `differ == 0` is also the statement that the test never rejects wrongly.  The
+device evaluates the test in fp32 on per-view tables with a margin of 1e-5; the checker also evaluates it in fp64 with
+the margin of 1e-12 that the proof in pt_packet.h is written for and counts the triangles only the fp32 form leaves
+out (`loose`, must be 0): the fp32 form is the weaker test."""
 import ctypes as C
 import os
 import subprocess
@@ -11,7 +14,7 @@ import pytest
 
 from conftest import ROOT, scene_path
 
-NAMES = "packets rays node_visits lists list_entries survivors lane_tests any_pass pushes pops max_depth ref_nodes ref_tris".split()
+NAMES = "packets rays node_visits lists list_entries survivors lane_tests any_pass pushes pops max_depth ref_nodes ref_tris loose kept64".split()
 
 
 @pytest.fixture(scope="module")
@@ -68,12 +71,13 @@ def test_packet_search_is_the_reference_search_for_every_camera_ray(checker, tmp
         assert rays > 0
         assert differ == 0, (name, eye, angle, rb)
         assert notes_differ == 0, (name, eye, angle, rb)
+        assert st["loose"] == 0, "the fp32 packet test left out a triangle that the fp64 form of the test keeps"
         total += rays
         for k in NAMES:
             agg[k] = max(agg[k], st[k]) if k == "max_depth" else agg[k] + st[k]
     p = agg["packets"]
     print(name, f"{total} rays in {p} packets; per packet: {agg['node_visits'] / p:.1f} nodes, {agg['list_entries'] / p:.1f} list entries, "
-          f"{agg['survivors'] / p:.1f} kept by the packet test, {agg['any_pass'] / p:.1f} hit by some ray; deepest stack {agg['max_depth']}; "
+          f"{agg['survivors'] / p:.1f} kept by the packet test ({agg['kept64'] / p:.1f} by its fp64 form), {agg['any_pass'] / p:.1f} hit by some ray; deepest stack {agg['max_depth']}; "
           f"per ray alone: {agg['ref_nodes'] / total:.1f} nodes, {agg['ref_tris'] / total:.1f} triangles")
     assert total > 100000
     # the packet test pays: it keeps a small part of the list entries
