@@ -72,49 +72,72 @@ __global__ void k_packet_prep(DevScene S, ViewParams V, float4 *forms) {
 // Primary pass, first kernel: the search of castRay at depth 0 (main.cpp:43 / mainOMP.cpp:39) for every sub-ray, one
 // packet per wave.  Writes the hit record of each sub-ray and, for the mainOMP model, whether the second search of
 // mainOMP.cpp:60 has to be run (SearchNote); k_primary_shade does the rest of castRay from that record.
+// The kernel's arguments are one struct, read where they are needed through the kernel-argument pointer made opaque to
+// the compiler: what the walk does not need (the view, the output arrays) then does not sit in scalar registers while it runs.
+struct PrimaryArgs { DevScene S; ViewParams V; FrameBuffers F; SubBuffers B; uint32_t nblocks; };
+typedef const PrimaryArgs __attribute__((address_space(4))) *PrimaryArgsU;
+PT_DEV PrimaryArgsU primary_args() {
+    PrimaryArgsU p = (PrimaryArgsU)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+PT_DEV ViewParams primary_view(PrimaryArgsU a) {
+    ViewParams V;
+    V.eye[0] = a->V.eye[0]; V.eye[1] = a->V.eye[1]; V.eye[2] = a->V.eye[2];
+    V.zoom = a->V.zoom; V.sa = a->V.sa; V.ca = a->V.ca; V.size = a->V.size; V.rb = a->V.rb; V.off = a->V.off;
+    V.seed = a->V.seed; V.view = a->V.view; V.model = a->V.model; V.part = a->V.part; V.n_parts = a->V.n_parts;
+    return V;
+}
 template <int MODEL>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_WAVES, PT_PKT_WAVES))) k_primary_search(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B, uint32_t nblocks) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_WAVES, PT_PKT_WAVES))) k_primary_search(PrimaryArgs A) {
     extern __shared__ double stack_lds[];
     const uint32_t lane = threadIdx.x & 63;
     uint32_t nprimary = 0;
     // persistent waves: a launched block (it owns a region of the stack overflow buffer) draws work blocks from a counter
     for (;;) {
+        const PrimaryArgsU a0 = primary_args();
         uint32_t blk = 0;
-        if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_PRIMARY], 1ull);
+        if (lane == 0) blk = (uint32_t)atomicAdd(&a0->F.counters[RC_WORK_PRIMARY], 1ull);
         blk = __builtin_amdgcn_readfirstlane(blk);
-        if (blk >= nblocks) break;
+        if (blk >= a0->nblocks) break;
         int i = 0, j = 0, sub = 4;
-        const bool live = packet_pixel(V, blk, lane, i, j, sub) && own_row(V.part, V.n_parts, i);
-        if (!__ballot(live)) continue;
-        const RayD ray = sub_ray(V, i, j, sub);      // lanes that are not live get a ray too: same origin, never searched
-        const PacketBoundsF PB = packet_bounds_f(packet_bounds(V.sa, V.ca, ray.dir, live));
+        bool live;
+        RayD ray;
+        PacketBoundsF PB;
+        {
+            const ViewParams V = primary_view(a0);
+            live = packet_pixel(V, blk, lane, i, j, sub) && own_row(V.part, V.n_parts, i);
+            if (!__ballot(live)) continue;
+            ray = sub_ray(V, i, j, sub);             // lanes that are not live get a ray too: same origin, never searched
+            PB = packet_bounds_f(packet_bounds(V.sa, V.ca, ray.dir, live));
+        }
         HitD h;
         h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
         SearchNote note;
-        const bool ok = MODEL == PT_MODEL_OMP ? packet_search<true>(S, ray, live, PB, B.forms, h, &note, stack_lds)
-                                              : packet_search<false>(S, ray, live, PB, B.forms, h, nullptr, stack_lds);
+        const bool ok = MODEL == PT_MODEL_OMP ? packet_search<true>(A.S, ray, live, PB, A.B.forms, h, &note, stack_lds)
+                                              : packet_search<false>(A.S, ray, live, PB, A.B.forms, h, nullptr, stack_lds);
+        const PrimaryArgsU a1 = primary_args();
+        const int size = a1->V.size, rb = a1->V.rb;
+        const size_t p = (size_t)i * size + j, slot = rb ? p * 9 + sub : p;
         const bool again = MODEL == PT_MODEL_OMP && live && ok && note.may_find_closer(h.tmin);
         if (MODEL == PT_MODEL_OMP) {                 // the few sub-rays whose second search has to be run go on a list (k_primary_again)
             const unsigned long long am = __ballot(again);
             if (am) {
                 uint32_t base = 0;
-                if (lane == (uint32_t)__builtin_ctzll(am)) base = (uint32_t)atomicAdd(&F.counters[RC_AGAIN], (unsigned long long)__popcll(am));
+                if (lane == (uint32_t)__builtin_ctzll(am)) base = (uint32_t)atomicAdd(&a1->F.counters[RC_AGAIN], (unsigned long long)__popcll(am));
                 base = __builtin_amdgcn_readlane(base, __builtin_ctzll(am));
-                if (again) {
-                    const size_t p = (size_t)i * V.size + j;
-                    B.again_list[base + __popcll(am & ((1ull << lane) - 1ull))] = (uint32_t)(V.rb ? p * 9 + sub : p);
-                }
+                if (again) a1->B.again_list[base + __popcll(am & ((1ull << lane) - 1ull))] = (uint32_t)slot;
             }
         }
         if (!live) continue;
         nprimary++;
-        const size_t p = (size_t)i * V.size + j, slot = V.rb ? p * 9 + sub : p;
-        B.found[slot] = ok ? 1 : 0; B.tri[slot] = ok ? h.tri : -1;
-        B.tuv[3 * slot] = ok ? h.tmin : -1.0; B.tuv[3 * slot + 1] = h.u; B.tuv[3 * slot + 2] = h.v;
-        B.again[slot] = again ? 1 : 0;
+        a1->B.found[slot] = ok ? 1 : 0; a1->B.tri[slot] = ok ? h.tri : -1;
+        double *tuv = a1->B.tuv + 3 * slot;
+        tuv[0] = ok ? h.tmin : -1.0; tuv[1] = h.u; tuv[2] = h.v;
+        a1->B.again[slot] = again ? 1 : 0;
     }
     const uint32_t total = wave_sum(nprimary);
-    if (lane == 0 && total) atomicAdd(&F.counters[RC_PRIMARY], (unsigned long long)total);
+    if (lane == 0 && total) atomicAdd(&primary_args()->F.counters[RC_PRIMARY], (unsigned long long)total);
 }
 
 // castRay at depth 0 after its search (main.cpp:44-78 / mainOMP.cpp:40-78) up to its mirror bounce, for the sub-ray in
@@ -435,17 +458,19 @@ int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F,
     const unsigned blocks = V.rb ? (unsigned)(((size_t)tile_threads(V.size) * 9 + 62) / 63) : (unsigned)(tile_threads(V.size) / 64);
     const unsigned pblocks = packet_blocks(V.size, V.rb);
     if (S.n_ref > 0) hipLaunchKernelGGL(k_packet_prep, dim3(((unsigned)S.n_ref + 255u) / 256u), dim3(256), 0, s, S, V, B.forms);
+    PrimaryArgs PA;
+    PA.S = S; PA.V = V; PA.F = F; PA.B = B; PA.nblocks = pblocks;
     if (V.model == PT_MODEL_MAIN) {
         static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_MAIN>, PT_EXACT_WAVES), wp = resident_waves(k_primary_shade<PT_MODEL_MAIN>, PT_EXACT_WAVES),
                               wm = resident_waves(k_mirror_exact<PT_MODEL_MAIN>, PT_EXACT_WAVES);
-        hipLaunchKernelGGL(k_primary_search<PT_MODEL_MAIN>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, pblocks);
+        hipLaunchKernelGGL(k_primary_search<PT_MODEL_MAIN>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_RING64_LDS_BYTES, s, PA);
         hipLaunchKernelGGL(k_primary_shade<PT_MODEL_MAIN>, dim3(blocks < wp ? blocks : wp), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         if (S.any_mirror) hipLaunchKernelGGL(k_mirror_exact<PT_MODEL_MAIN>, dim3(blocks < wm ? blocks : wm), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         hipLaunchKernelGGL(k_primary_combine<PT_MODEL_MAIN>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb, V.part, V.n_parts);
     } else {
         static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_OMP>, PT_EXACT_WAVES), wm = resident_waves(k_mirror_exact<PT_MODEL_OMP>, PT_EXACT_WAVES);
         const size_t slots = P * (V.rb ? 9 : 1);
-        hipLaunchKernelGGL(k_primary_search<PT_MODEL_OMP>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, pblocks);
+        hipLaunchKernelGGL(k_primary_search<PT_MODEL_OMP>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_RING64_LDS_BYTES, s, PA);
         const size_t sblocks = (slots + 255) / 256;
         hipLaunchKernelGGL(k_primary_shade_omp, dim3((unsigned)(sblocks < 2048 ? sblocks : 2048)), dim3(256), 0, s, S, V, F, B);
         // the listed sub-rays: few, so a grid of one wave per SIMD-quarter of the chip is plenty (the list's length is on the device)

@@ -24,6 +24,16 @@
 #define PT_PKT_WAVES 4                     // waves per SIMD the search kernel is compiled for
 #endif
 
+// PT_PKT_CLOCKS (an instrumented build for tools/pkt_clocks.py, never the product): wave clocks per part of the walk.
+#ifdef PT_PKT_CLOCKS
+__device__ unsigned long long g_pkt_clk[16];
+#define PKT_T0() unsigned long long pkt_t_ = __builtin_amdgcn_s_memtime()
+#define PKT_LAP(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pkt_acc_[slot] += n_ - pkt_t_; pkt_cnt_[slot]++; pkt_t_ = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PKT_T0() do {} while (0)
+#define PKT_LAP(slot) do {} while (0)
+#endif
+
 PT_DEV double wave_min_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
@@ -283,66 +293,60 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, cons
     bool found = false, at_leaf = false;
     unsigned long long act = __ballot(in);
     int curr = 0;
-    NodeA nd = load_node_u(S, 0);
+    // One loop with one back edge: a turn pops an entry if no ray is in the current node, and then, if some ray is in
+    // the (new) current node, does that node.
     for (;;) {
         if (!act) {
-            if (!NOTED && !__ballot(!finished)) break;
-            while (st.sp > 0 && !act) {
-                unsigned long long pushm, deferm;
-                st.pop(curr, pushm, deferm);
-                in = (deferm >> lane) & 1ull;
-                if ((pushm >> lane) & 1ull) {
-                    double e, x;
-                    st.popped(e, x);
-                    if (finished) { if (NOTED && e < note->stack_min) note->stack_min = e; }
-                    else if (e >= h.tmin) finished = true;          // util/kdtree.cpp:229-231: ends this ray's search
-                    else { ent = e; ext = x; in = true; }
-                }
-                act = __ballot(in);
+            if (st.sp == 0 || (!NOTED && !__ballot(!finished))) break;
+            unsigned long long pushm, deferm;
+            st.pop(curr, pushm, deferm);
+            in = (deferm >> lane) & 1ull;
+            if ((pushm >> lane) & 1ull) {
+                double e, x;
+                st.popped(e, x);
+                if (finished) { if (NOTED && e < note->stack_min) note->stack_min = e; }
+                else if (e >= h.tmin) finished = true;          // util/kdtree.cpp:229-231: ends this ray's search
+                else { ent = e; ext = x; in = true; }
             }
-            if (!act) break;
-            nd = load_node_u(S, curr);
+            act = __ballot(in);
         }
-        const double split = nd.split;
-        const int axis = nd.axis, left = nd.left;
-        // both children are asked for before this node's list is gone through: one of them is the next node
-        NodeA c0 = nd, c1 = nd;
-        if (PT_PKT_PRE_NODE && axis >= 0) { c0 = load_node_u(S, left); c1 = load_node_u(S, left + 1); }
-        bool improved = false;
-        if (nd.count > 0) improved = packet_node(S, curr, nd.first, nd.count, ray, in, B, forms, h);
-        if (axis < 0) {                              // a leaf: the rays that improved their hit here are done (:252-253)
-            if (in && improved) { at_leaf = true; finished = true; }
-            act = 0;
-            continue;
-        }
-        found |= in && improved;
-        const double sa = axis == 0 ? pr.ox : (axis == 1 ? pr.oy : pr.oz);
-        const double tdir = axis == 0 ? pr.tx : (axis == 1 ? pr.ty : pr.tz);
-        const double tmid = (split - sa) / tdir;
-        const bool near_only = tmid >= ext || tmid < 0;
-        const bool far_only = !near_only && tmid <= ent && tmid <= h.tmin;
-        const bool push = !near_only && !far_only && tmid <= h.tmin;
-        const unsigned long long nearm = __ballot(in && !far_only), farm = __ballot(in && far_only), pushm = __ballot(in && push);
-        if (NOTED && in && far_only && tmid > note->far_max) note->far_max = tmid;
-        const bool swap = sa > split;                // the same for every ray: they share src
-        const int nr = swap ? left + 1 : left, fr = swap ? left : left + 1;
-        if (nearm) {
-            if (farm | pushm) {
-                if (st.sp >= 64u || (st.sp >= PT_PKT_LDS && (st.sp - PT_PKT_LDS) * 2u + 2u > S.ovf64_entries * 3u)) {
-                    atomicOr(S.err, (unsigned long long)PT_LIMIT_F64_STACK);      // cannot happen for a tree of the uploaded depth
-                    return false;
+        if (act) {
+            const NodeA nd = load_node_u(S, curr);
+            const int axis = nd.axis, left = nd.left;
+            bool improved = false;
+            if (nd.count > 0) improved = packet_node(S, curr, nd.first, nd.count, ray, in, B, forms, h);
+            if (axis < 0) {                          // a leaf: the rays that improved their hit here are done (:252-253)
+                if (in && improved) { at_leaf = true; finished = true; }
+                act = 0;
+            } else {
+                found |= in && improved;
+                const double sa = axis == 0 ? pr.ox : (axis == 1 ? pr.oy : pr.oz);
+                const double tdir = axis == 0 ? pr.tx : (axis == 1 ? pr.ty : pr.tz);
+                const double tmid = (nd.split - sa) / tdir;
+                const bool near_only = tmid >= ext || tmid < 0;
+                const bool far_only = !near_only && tmid <= ent && tmid <= h.tmin;
+                const bool push = !near_only && !far_only && tmid <= h.tmin;
+                const unsigned long long nearm = __ballot(in && !far_only), farm = __ballot(in && far_only), pushm = __ballot(in && push);
+                if (NOTED && in && far_only && tmid > note->far_max) note->far_max = tmid;
+                const bool swap = sa > nd.split;     // the same for every ray: they share src
+                const int nr = swap ? left + 1 : left, fr = swap ? left : left + 1;
+                if (nearm) {
+                    if (farm | pushm) {
+                        if (st.sp >= 64u || (st.sp >= PT_PKT_LDS && (st.sp - PT_PKT_LDS) * 2u + 2u > S.ovf64_entries * 3u)) {
+                            atomicOr(S.err, (unsigned long long)PT_LIMIT_F64_STACK);  // cannot happen for a tree of the uploaded depth
+                            st.sp = 0; act = 0; finished = true;                      // ends the walk
+                        } else {
+                            st.push(fr, pushm, farm, in && push, tmid, ext);
+                        }
+                    }
+                    if (in && !near_only && !far_only) ext = tmid;
+                    in = in && !far_only;
+                    curr = nr; act = act ? nearm : 0;
+                } else {
+                    curr = fr; act = farm;
                 }
-                st.push(fr, pushm, farm, in && push, tmid, ext);
             }
-            if (in && !near_only && !far_only) ext = tmid;
-            in = in && !far_only;
-            curr = nr; act = nearm;
-            nd = swap ? c1 : c0;
-        } else {
-            curr = fr; act = farm;
-            nd = swap ? c0 : c1;
         }
-        if (!PT_PKT_PRE_NODE) nd = load_node_u(S, curr);
     }
     return at_leaf || found;
 }
