@@ -125,6 +125,7 @@ typedef struct PtStats {
     double ms_gi_trace;       /* device time of the GI closest-hit kernels */
     uint64_t gi_trace_launches;
     uint64_t gi_nodes_visited, gi_tris_tested;   /* only with PT_FLAG_COUNT_WORK */
+    double ms_primary;        /* device time of the primary pass (ray generation, fp64 search, shading, mirror bounce) */
 } PtStats;
 
 typedef struct PtScene PtScene;
@@ -201,14 +202,16 @@ int pt_render_views(PtScene *scene, const PtCamera *cams, size_t n, uint32_t vie
 int pt_trace(PtScene *scene, size_t n, const double *src, const double *dir, const double *tmin_in, int mode,
              int32_t *found, int32_t *mesh, int32_t *tri, double *t, double *u, double *v);
 
-/* pt_trace mode 1 (the fp32 nearest-hit search) for callers that cannot allocate: code under HIP graph capture,
-   tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  All ten arrays
+/* pt_trace mode 1 (the fp32 nearest-hit search) for callers that cannot allocate: tight serving loops, harnesses
+   that forbid hipMalloc.  (Not for a stream under graph capture: the call synchronises its own stream and reads a
+   word back.)  It has no counterpart in the reference.  All ten arrays
    are DEVICE memory on the device chosen by pt_init (layouts as in pt_trace; d_mesh / d_tri receive the (mesh, tri)
    pair); the call runs on the scene's stream and returns when the outputs are complete.  It calls no hipMalloc,
    hipFree or other allocating routine: the kernel's scratch (queue heads and the traversal overflow stack) is a
    fixed 32 MiB array inside the library's code object, one copy per GPU for the life of the process.
    Limits, refused with PT_ERR_LIMIT: n <= 2^24 rays per call; fp32 device tree at most 62 levels deep
-   (PtSceneInfo.dev_depth).  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU race. */
+   (PtSceneInfo.dev_depth).  Every call on a GPU uses that GPU's one array, so the library serialises the calls on a
+   GPU, whatever scenes they are for; the caller's current device is left as it was. */
 int pt_trace_device(PtScene *scene, size_t n, const double *d_src, const double *d_dir, const double *d_tmin_in,
                     int32_t *d_found, int32_t *d_mesh, int32_t *d_tri, double *d_t, double *d_u, double *d_v);
 

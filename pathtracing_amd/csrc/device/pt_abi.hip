@@ -69,9 +69,12 @@ struct Workspace {
 }  // namespace
 
 // Header of a scene slab (the one device allocation that holds every immutable array of a scene).
+#define PT_SLAB_MAX_ARRAYS 32
 struct SlabHeader {
-    char magic[8];                    // "PTSLAB02"
+    char magic[8];                    // "PTSLAB03"
     uint64_t total_bytes;             // header + arrays
+    uint64_t array_bytes[PT_SLAB_MAX_ARRAYS];   // size of each array, in the order of PT_SLAB_POINTERS
+    uint64_t body_check;              // slab_body_check() of everything after the header
     DevScene S;                       // pointer fields of PT_SLAB_POINTERS: byte offsets from the slab's start; scratch pointers null
     RefineStats refine;
     int32_t max_depth;                // host tree
@@ -89,6 +92,7 @@ struct PtScene {
     hipStream_t stream = nullptr;
     hipStream_t stream_gen = nullptr;         // ray generation of the next GI pass runs here, beside the current pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;   // around the primary pass of a view
     std::vector<hipEvent_t> pass_events;      // a pair per GI pass of a view (fp32 path), grown on demand
     int max_depth = 0;
     RefineStats refine;
@@ -101,9 +105,62 @@ struct PtScene {
     std::mutex busy;                            // calls on one scene are serialised: it has one workspace, one stream pair
 };
 
+// Checksum of a slab's body (everything after the header), the same number on the host and on the device: the sum over
+// the body's 64-bit words of a mix of (word, position).  A sum, so that any number of threads can each take a part.
+__host__ __device__ inline uint64_t slab_word_mix(uint64_t w, uint64_t i) {
+    uint64_t z = w + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void k_slab_body_check(const uint64_t *words, size_t n, unsigned long long *out) {
+    uint64_t a = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a += slab_word_mix(words[i], i);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor((unsigned long long)a, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)a);
+}
+
 namespace {
 
-std::vector<int> g_devices;           // the devices pt_init selected; g_device is the first of them
+std::vector<int> g_devices;
+
+constexpr size_t kSlabBody = (sizeof(SlabHeader) + 255) & ~(size_t)255;       // where the arrays begin
+
+uint64_t slab_body_check_host(const uint8_t *slab, size_t total) {
+    const size_t n = (total - kSlabBody) / 8;
+    const uint8_t *body = slab + kSlabBody;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+    std::vector<uint64_t> part(nt, 0);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            uint64_t a = 0;
+            for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) { uint64_t w; std::memcpy(&w, body + 8 * i, 8); a += slab_word_mix(w, i); }
+            part[t] = a;
+        });
+    uint64_t a = 0;
+    for (unsigned t = 0; t < nt; t++) { th[t].join(); a += part[t]; }
+    return a;
+}
+
+// The same over a slab in memory of the current device.
+int slab_body_check_device(const uint8_t *slab, size_t total, uint64_t *out) {
+    unsigned long long *d = nullptr;
+    if (hipMalloc((void **)&d, sizeof *d) != hipSuccess) return fail(PT_ERR_OOM, "out of device memory (slab check)");
+    hipError_t e = hipMemset(d, 0, sizeof *d);
+    const size_t n = (total - kSlabBody) / 8;
+    if (e == hipSuccess && n) {
+        hipLaunchKernelGGL(k_slab_body_check, dim3(2048), dim3(256), 0, 0, (const uint64_t *)(slab + kSlabBody), n, d);
+        e = hipGetLastError();
+    }
+    unsigned long long v = 0;
+    if (e == hipSuccess) e = hipMemcpy(&v, d, sizeof v, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PT_ERR_HIP, std::string("slab check: ") + hipGetErrorString(e));
+    *out = v;
+    return PT_OK;
+}           // the devices pt_init selected; g_device is the first of them
 
 // FNV-1a over the header's bytes as they lie in memory (padding included: a header is only ever moved with memcpy),
 // the check field itself left out.
@@ -120,6 +177,7 @@ uint64_t header_check(const SlabHeader &h) {
 // header's DevScene.
 struct SlabBuilder {
     std::vector<uint8_t> bytes;
+    std::vector<std::pair<size_t, size_t>> placed;         // (offset, bytes) of every array added
     SlabHeader hdr;
     SlabBuilder() {
         std::memset((void *)&hdr, 0, sizeof hdr);          // padding bytes too: the header is hashed as bytes
@@ -130,6 +188,7 @@ struct SlabBuilder {
         const size_t off = bytes.size(), nb = n * sizeof(T);
         bytes.resize((off + (nb ? nb : 1) + 255) & ~(size_t)255);
         if (nb) std::memcpy(bytes.data() + off, src, nb);
+        placed.push_back({off, nb});
         hdr.S.*field = (const T *)(uintptr_t)off;
     }
 };
@@ -371,19 +430,63 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
     if (const char *e = getenv("PT_TUNE_OVF_DEPTH")) { int k = atoi(e); if (k >= 1 && (uint32_t)k < S.ovf_depth) S.ovf_depth = (uint32_t)k; }
     S.ovf_waves = PT_TRACE_WAVES;
     S.ovf64_entries = (uint32_t)depth + 2u;
-    std::memcpy(H.magic, "PTSLAB02", 8);
+    std::memcpy(H.magic, "PTSLAB03", 8);
     H.total_bytes = B.bytes.size();
+    {
+        size_t k = 0;
+#define X(f) { const size_t off = (size_t)(uintptr_t)S.f; for (const auto &pl : B.placed) if (pl.first == off) H.array_bytes[k] = pl.second; k++; }
+        PT_SLAB_POINTERS(X)
+#undef X
+        static_assert(sizeof(uint64_t) * PT_SLAB_MAX_ARRAYS == sizeof H.array_bytes, "array table");
+    }
+    H.body_check = slab_body_check_host(B.bytes.data(), B.bytes.size());
     H.check = header_check(H);
     std::memcpy(B.bytes.data(), &H, sizeof H);
     return PT_OK;
 }
 
+// Is this the header of a slab that this version of the library wrote, intact, and do the arrays it describes lie inside
+// the `bytes` of the block and have the sizes the kernels will assume from the scene's counts?  (What is IN the arrays --
+// node links, triangle offsets, indices -- is covered by the body checksum, compared once the block is on the device.)
 int check_slab_header(const SlabHeader &H, size_t bytes) {
-    if (std::memcmp(H.magic, "PTSLAB02", 8) != 0 || H.total_bytes != bytes || bytes < sizeof(SlabHeader) || H.check != header_check(H))
+    if (std::memcmp(H.magic, "PTSLAB03", 8) != 0 || H.total_bytes != bytes || bytes < kSlabBody || (bytes & 7) || H.check != header_check(H))
         return fail(PT_ERR_INVALID, "not a scene slab of this library version, or damaged");
-#define X(f) if ((uintptr_t)H.S.f < sizeof(SlabHeader) || (uintptr_t)H.S.f >= bytes) return fail(PT_ERR_INVALID, "scene slab: array offset out of range");
+    const DevScene &S = H.S;
+    if (S.n_node < 1 || S.n_ref < 0 || S.n_tri < 0 || S.n_light < 0 || (uint64_t)S.n_tri != H.n_tri)
+        return fail(PT_ERR_INVALID, "scene slab: counts out of range");
+    size_t k = 0;
+#define X(f) { const uint64_t off = (uint64_t)(uintptr_t)S.f, nb = H.array_bytes[k++]; \
+               if (off < kSlabBody || off > bytes || nb > bytes - off) return fail(PT_ERR_INVALID, "scene slab: array " #f " outside the block"); }
     PT_SLAB_POINTERS(X)
 #undef X
+    // sizes the kernels rely on, from the counts they index with
+    struct Want { uint64_t have, want; const char *what; };
+    k = 0;
+    uint64_t have[PT_SLAB_MAX_ARRAYS] = {};
+#define X(f) have[k] = H.array_bytes[k]; k++;
+    PT_SLAB_POINTERS(X)
+#undef X
+    k = 0;
+#define X(f) const size_t i_##f = k++;
+    PT_SLAB_POINTERS(X)
+#undef X
+    const uint64_t nn = (uint64_t)S.n_node, nr = (uint64_t)S.n_ref, nt = (uint64_t)S.n_tri, nl = (uint64_t)S.n_light;
+    const Want wants[] = {
+        {have[i_nodeA], nn * sizeof(NodeA), "nodeA"}, {have[i_nodeBox], nn * 48, "nodeBox"}, {have[i_refTri], nr * 72, "refTri"},
+        {have[i_refId], nr * 4, "refId"}, {have[i_nodeF], H.refine.nodes * sizeof(NodeF), "nodeF"}, {have[i_refTriF], H.refine.refs * 48, "refTriF"},
+        {have[i_triGeo], nt * 72, "triGeo"}, {have[i_triNgF], nt * 16, "triNgF"}, {have[i_tri_ni], nt * 12, "tri_ni"}, {have[i_tri_ti], nt * 12, "tri_ti"},
+        {have[i_tri_tm], nt * 4, "tri_tm"}, {have[i_tri_reft], nt * 4, "tri_reft"}, {have[i_tri_mesh], nt * 4, "tri_mesh"},
+        {have[i_tri_local], nt * 4, "tri_local"}, {have[i_triShadeF], nt * 80, "triShadeF"}, {have[i_albedo], (uint64_t)H.n_mesh * 24, "albedo"},
+        {have[i_lights], nl * sizeof(PtLight), "lights"}, {have[i_lightsF], nl * 32, "lightsF"},
+    };
+    for (const Want &w : wants)
+        if (w.have != w.want) return fail(PT_ERR_INVALID, std::string("scene slab: array ") + w.what + " does not have the size its count asks for");
+    if (have[i_tex_off] / 8 != have[i_tex_rows] / 4 || have[i_tex_rows] != have[i_tex_cols] || (S.has_quads && have[i_quadF] < 16))
+        return fail(PT_ERR_INVALID, "scene slab: texture or quad tables inconsistent");
+    // scratch every copy allocates from these: keep them in the range build_slab can produce
+    if (S.ovf_waves != PT_TRACE_WAVES || S.ovf_depth < 1 || S.ovf_depth > 4096 || S.ovf64_entries < 2 || S.ovf64_entries > PT_STACK_MAX + 2 ||
+        H.max_depth < 0 || H.max_depth >= PT_STACK_MAX)
+        return fail(PT_ERR_INVALID, "scene slab: scratch sizes out of range");
     return PT_OK;
 }
 
@@ -426,6 +529,8 @@ int finish_scene(uint8_t *slab, const SlabHeader &H, int device, PtScene **out, 
     if (e == hipSuccess) e = hipStreamCreate(&sc->stream_gen);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev0);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&sc->ev_p0);
+    if (e == hipSuccess) e = hipEventCreate(&sc->ev_p1);
     if (e != hipSuccess) return fail(PT_ERR_HIP, std::string("stream/event creation: ") + hipGetErrorString(e));
     *out = holder.release();
     return PT_OK;
@@ -447,6 +552,12 @@ int scene_from_slab(const void *src, size_t bytes, bool src_is_device, PtScene *
     hipError_t e = hipMemcpy(slab, src, bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipDeviceSynchronize();      // the caller may free or reuse `src` as soon as this returns
     if (e != hipSuccess) { (void)hipFree(slab); return fail(PT_ERR_HIP, std::string("scene slab copy: ") + hipGetErrorString(e)); }
+    // the body as it arrived: a block that another process or rank built travels unchecked otherwise, and the kernels
+    // follow its node links and triangle offsets without looking
+    uint64_t body = 0;
+    rc = slab_body_check_device((const uint8_t *)slab, bytes, &body);
+    if (!rc && body != H.body_check) rc = fail(PT_ERR_INVALID, "scene slab: the arrays do not match the header's checksum (damaged or truncated in transit)");
+    if (rc) { (void)hipFree(slab); return rc; }
     return finish_scene((uint8_t *)slab, H, g_device, out);
 }
 
@@ -583,7 +694,9 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     // the kernels of a view report tripped limits in the last word of the view's counter block, read with the counters
     DevScene S = sc->S;
     S.err = F.counters + RC_LIMITS;
+    if (st) HIPCHK(hipEventRecord(sc->ev_p0, s));
     if (exact_primary(S, V, F, sc->ws.B, s)) return fail(PT_ERR_HIP, "primary pass launch failed");
+    if (st) HIPCHK(hipEventRecord(sc->ev_p1, s));
     *gi_ms = 0; *gi_launches = 0;
     uint64_t fast_rays = 0, fast_shadow = 0, fast_work[2] = {0, 0};
     const bool count_work = fast && (o->flags & PT_FLAG_COUNT_WORK);
@@ -612,6 +725,9 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     HIPCHK(hipStreamSynchronize(s));
     if (c[RC_LIMITS]) return fail(PT_ERR_LIMIT, limit_message("render", c[RC_LIMITS]));
     if (st) {
+        float pms = 0;
+        HIPCHK(hipEventElapsedTime(&pms, sc->ev_p0, sc->ev_p1));
+        st->ms_primary += pms;
         st->primary += c[RC_PRIMARY]; st->shadow += c[RC_SHADOW]; st->mirror += c[RC_MIRROR];
         st->gi += c[RC_GI] + fast_rays; st->shadow += fast_shadow; st->omp_retrace += c[RC_RETRACE];
         st->ms_gi_trace += *gi_ms; st->gi_trace_launches += *gi_launches;
@@ -839,6 +955,8 @@ int pt_scene_free(PtScene *sc) {
     if (sc->slab && !sc->slab_borrowed) (void)hipFree(sc->slab);
     if (sc->ev0) (void)hipEventDestroy(sc->ev0);
     if (sc->ev1) (void)hipEventDestroy(sc->ev1);
+    if (sc->ev_p0) (void)hipEventDestroy(sc->ev_p0);
+    if (sc->ev_p1) (void)hipEventDestroy(sc->ev_p1);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
     if (sc->stream_gen) (void)hipStreamDestroy(sc->stream_gen);
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
@@ -1063,42 +1181,71 @@ int pt_render_views(PtScene *sc, const PtCamera *cams, size_t n, uint32_t view0,
     std::vector<std::string> werr(W);
     std::vector<PtStats> wst(W);
     std::atomic<size_t> next_view{0};
-    std::atomic<bool> stop{false};                         // a worker failed: the others take no further view
+    std::vector<long long> wfailed(W, -1);                 // the view a worker failed on (it takes no further view)
+    // PT_TUNE_FAIL_VIEW=i: the first attempt at view i of the call fails (a test of the second attempt)
+    long long inject = -1;
+    if (const char *e = getenv("PT_TUNE_FAIL_VIEW")) inject = atoll(e);
+    std::atomic<bool> injected{false};
+    auto one_view = [&](PtScene *my, PtStats *st, size_t i) -> int {
+        PtOptions o = *opt;
+        o.view = view0 + (uint32_t)i * view_stride;
+        if ((long long)i == inject && !injected.exchange(true)) return fail(PT_ERR_HIP, "injected failure (PT_TUNE_FAIL_VIEW)");
+        float gi_ms; uint64_t gi_l;
+        int r = render_on_device(my, &cams[i], &o, st, &gi_ms, &gi_l);
+        // the copy is ordered on the scene's stream; the next view's kernels follow it
+        if (!r && hipMemcpyAsync(frames + i * frame_bytes, my->ws.F.bgr, frame_bytes, hipMemcpyDeviceToHost, my->stream) != hipSuccess)
+            r = fail(PT_ERR_HIP, "frame copy failed");
+        return r;
+    };
     auto work = [&](size_t w) {
         PtScene *my = workers[w];
         PtStats *st = stats ? &wst[w] : nullptr;
         if (st) std::memset(st, 0, sizeof *st);
         int r = PT_OK;
         if (hipSetDevice(my->device) != hipSuccess) r = fail(PT_ERR_HIP, "hipSetDevice failed in a view worker");
-        PtOptions o = *opt;
-        for (size_t i; !r && !stop.load() && (i = next_view.fetch_add(1)) < n;) {
-            o.view = view0 + (uint32_t)i * view_stride;
-            float gi_ms; uint64_t gi_l;
-            r = render_on_device(my, &cams[i], &o, st, &gi_ms, &gi_l);
-            // the copy is ordered on the scene's stream; the next view's kernels follow it
-            if (!r && hipMemcpyAsync(frames + i * frame_bytes, my->ws.F.bgr, frame_bytes, hipMemcpyDeviceToHost, my->stream) != hipSuccess)
-                r = fail(PT_ERR_HIP, "frame copy failed");
+        for (size_t i; !r && (i = next_view.fetch_add(1)) < n;) {
+            r = one_view(my, st, i);
+            if (r) wfailed[w] = (long long)i;
         }
-        if (!r && hipStreamSynchronize(my->stream) != hipSuccess) r = fail(PT_ERR_HIP, "stream synchronisation failed");
+        // whatever happened, no copy into the caller's `frames` is in flight on this worker's stream when the call returns
+        const hipError_t se = hipStreamSynchronize(my->stream);
+        if (!r && se != hipSuccess) r = fail(PT_ERR_HIP, "stream synchronisation failed");
         wrc[w] = r;
-        if (r) { werr[w] = g_error; stop.store(true); }    // the message lives in the worker's thread
+        if (r) werr[w] = g_error;                          // the message lives in the worker's thread
     };
     if (W == 1) {
         work(0);
     } else {
         std::vector<std::thread> threads;
-        for (size_t w = 0; w < W; w++) threads.emplace_back([&, w] { try { work(w); } catch (...) { wrc[w] = PT_ERR_OOM; werr[w] = "exception in a view worker"; stop.store(true); } });
+        for (size_t w = 0; w < W; w++) threads.emplace_back([&, w] { try { work(w); } catch (...) { wrc[w] = PT_ERR_OOM; werr[w] = "exception in a view worker"; } });
         for (std::thread &t : threads) t.join();
         (void)hipSetDevice(sc->device);
     }
-    for (size_t w = 0; w < W; w++)
-        if (wrc[w]) return fail(wrc[w], "view worker " + std::to_string(w) + " (device " + std::to_string(wdev[w]) + "): " + werr[w]);
+    // A worker that failed stopped at its view; the others went on and rendered the rest (the failed worker's share included).
+    // The failed view gets a second attempt on a worker that is in order (the reference has nothing of the kind: a
+    // worker that dies leaves rank 0 waiting in MPI_Recv, mainOMP.cpp:188); a second failure, or no worker left, ends the call.
+    for (size_t w = 0; w < W; w++) {
+        if (!wrc[w]) continue;
+        size_t good = W;
+        for (size_t k = 0; k < W && good == W; k++) if (!wrc[k]) good = k;
+        const std::string first = "view worker " + std::to_string(w) + " (device " + std::to_string(wdev[w]) + "): " + werr[w];
+        if (good == W || wfailed[w] < 0) return fail(wrc[w], first);
+        // views the failed worker never got to: the counter ran on, the other workers took them all; only its own view is open
+        PtScene *my = workers[good];
+        int r = hipSetDevice(my->device) == hipSuccess ? PT_OK : fail(PT_ERR_HIP, "hipSetDevice failed");
+        if (!r) r = one_view(my, stats ? &wst[good] : nullptr, (size_t)wfailed[w]);
+        const hipError_t se = hipStreamSynchronize(my->stream);
+        if (!r && se != hipSuccess) r = fail(PT_ERR_HIP, "stream synchronisation failed");
+        (void)hipSetDevice(sc->device);
+        if (r) return fail(r, first + "; second attempt at view " + std::to_string(wfailed[w]) + " on worker " + std::to_string(good) + ": " + g_error);
+        wrc[w] = PT_OK;
+    }
     if (stats) {
         for (size_t w = 0; w < W; w++) {
             stats->primary += wst[w].primary; stats->shadow += wst[w].shadow; stats->mirror += wst[w].mirror; stats->gi += wst[w].gi;
             stats->omp_retrace += wst[w].omp_retrace; stats->ms_gi_trace += wst[w].ms_gi_trace;
             stats->gi_trace_launches += wst[w].gi_trace_launches; stats->gi_nodes_visited += wst[w].gi_nodes_visited;
-            stats->gi_tris_tested += wst[w].gi_tris_tested;
+            stats->gi_tris_tested += wst[w].gi_tris_tested; stats->ms_primary += wst[w].ms_primary;
         }
         stats->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -1178,8 +1325,11 @@ int pt_trace(PtScene *sc, size_t n, const double *src, const double *dir, const 
 }); }
 
 // No allocation on this path: no hipMalloc / hipFree, no std::vector, no std::string unless the call fails.
+// The fixed scratch array is one per GPU, so the calls on one GPU are serialised whatever scene they are for
+// (a static mutex per device ordinal); the caller's current device is put back before the call returns.
+static std::mutex g_static_scratch_mutex[PT_STATIC_MAX_DEVICES];
 int pt_trace_device(PtScene *sc, size_t n, const double *d_src, const double *d_dir, const double *d_tmin_in,
-                    int32_t *d_found, int32_t *d_mesh, int32_t *d_tri, double *d_t, double *d_u, double *d_v) {
+                    int32_t *d_found, int32_t *d_mesh, int32_t *d_tri, double *d_t, double *d_u, double *d_v) { return guarded([&]() -> int {
     if (!sc) return fail(PT_ERR_INVALID, "scene is null");
     if (g_device < 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not been called");
     if (n == 0) return PT_OK;
@@ -1188,13 +1338,19 @@ int pt_trace_device(PtScene *sc, size_t n, const double *d_src, const double *d_
     if (n > PT_STATIC_MAX_RAYS) return fail(PT_ERR_LIMIT, "pt_trace_device: more than 2^24 rays in one call");
     if ((uint32_t)sc->refine.max_depth + 2u > PT_STATIC_DEPTH)            // this path walks the binary records: one stack entry per level
         return fail(PT_ERR_LIMIT, "pt_trace_device: the scene's fp32 tree is deeper than the fixed scratch stack (62 levels)");
-    std::lock_guard<std::mutex> lock(sc->busy);       // one scene, one stream; the fixed scratch array is per GPU (see the header)
+    if (sc->device < 0 || sc->device >= PT_STATIC_MAX_DEVICES) return fail(PT_ERR_LIMIT, "pt_trace_device: device ordinal beyond the scratch table");
+    std::lock_guard<std::mutex> device_lock(g_static_scratch_mutex[sc->device]);   // one scratch array per GPU
+    std::lock_guard<std::mutex> lock(sc->busy);                                    // one scene, one stream
+    int before = -1;
+    (void)hipGetDevice(&before);
     HIPCHK(hipSetDevice(sc->device));
     int rc = fast_trace_static(sc->S, sc->device, n, d_src, d_dir, d_tmin_in, d_found, d_mesh, d_tri, d_t, d_u, d_v, sc->stream);
-    if (rc == PT_ERR_HIP) return fail(rc, std::string("pt_trace_device: ") + hipGetErrorString(hipGetLastError()));
-    if (rc) return fail(rc, "pt_trace_device: no scratch address for this device (pt_init), or a size limit");
-    return check_limits(sc, "pt_trace_device");
-}
+    if (rc == PT_ERR_HIP) rc = fail(rc, std::string("pt_trace_device: ") + hipGetErrorString(hipGetLastError()));
+    else if (rc) rc = fail(rc, "pt_trace_device: no scratch address for this device (pt_init), or a size limit");
+    else rc = check_limits(sc, "pt_trace_device");
+    if (before >= 0 && before != sc->device) (void)hipSetDevice(before);
+    return rc;
+}); }
 
 int pt_camera_rays(const PtCamera *cam, int size, double x, double y, double *dir_out) {
     if (g_device < 0) return fail(PT_ERR_NO_DEVICE, "pt_init has not been called");

@@ -8,6 +8,10 @@
 #include "pt_frame.h"
 #include "pt_packet.h"
 
+// Work blocks a resident wave draws per update of a view's work counter: updates of one word run at some 90 per
+// microsecond on the whole chip, and a -rb view is 38 000 blocks.
+#define PT_WORK_DRAW 4u
+
 // 8x8 pixel tiles: one wave = one tile, so that the rays of a wave stay close.
 PT_DEV bool tile_pixel(int linear, int size, int &i, int &j) {
     int tiles_x = (size + 7) >> 3;
@@ -188,11 +192,13 @@ __global__ void __launch_bounds__(64) k_primary_shade(DevScene S, ViewParams V, 
 #pragma unroll
     for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
     const uint32_t lane = threadIdx.x & 63;
-    for (;;) {
-        uint32_t blk = 0;
-        if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_SHADE], 1ull);
-        blk = __builtin_amdgcn_readfirstlane(blk);
-        if (blk >= nblocks) break;
+    for (uint32_t blk = 0, blk_end = 0;; blk++) {
+        if (blk == blk_end) {                        // PT_WORK_DRAW work blocks per update of the counter
+            if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_SHADE], (unsigned long long)PT_WORK_DRAW);
+            blk = __builtin_amdgcn_readfirstlane(blk);
+            if (blk >= nblocks) break;
+            blk_end = blk + PT_WORK_DRAW < nblocks ? blk + PT_WORK_DRAW : nblocks;
+        }
         uint32_t lin;
         int sub = 4;
         bool live = true;
@@ -267,11 +273,13 @@ __global__ void __launch_bounds__(64) k_mirror_exact(DevScene S, ViewParams V, F
 #pragma unroll
     for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
     const uint32_t lane = threadIdx.x & 63;
-    for (;;) {
-        uint32_t blk = 0;
-        if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_MIRROR], 1ull);
-        blk = __builtin_amdgcn_readfirstlane(blk);
-        if (blk >= nblocks) break;
+    for (uint32_t blk = 0, blk_end = 0;; blk++) {
+        if (blk == blk_end) {                        // PT_WORK_DRAW work blocks per update of the counter
+            if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_MIRROR], (unsigned long long)PT_WORK_DRAW);
+            blk = __builtin_amdgcn_readfirstlane(blk);
+            if (blk >= nblocks) break;
+            blk_end = blk + PT_WORK_DRAW < nblocks ? blk + PT_WORK_DRAW : nblocks;
+        }
         uint32_t lin;
         int sub = 0;
         bool live = true;
@@ -441,9 +449,9 @@ __global__ void k_hemisphere(uint32_t seed, uint32_t view, uint32_t pixel, int n
 // block waits for another to finish: a second round of blocks would run at a fraction of the occupancy), at most
 // PT_EXACT_WAVES (the stack overflow regions) and at most the work.
 template <typename K>
-static unsigned resident_waves(K kernel, size_t work_blocks) {
+static unsigned resident_waves(K kernel, size_t work_blocks, size_t lds_bytes = PT_RING64_LDS_BYTES) {
     int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, PT_RING64_LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 8;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
         cus = 256;
     size_t w = (size_t)per_cu * (size_t)cus;
@@ -461,16 +469,16 @@ int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F,
     PrimaryArgs PA;
     PA.S = S; PA.V = V; PA.F = F; PA.B = B; PA.nblocks = pblocks;
     if (V.model == PT_MODEL_MAIN) {
-        static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_MAIN>, PT_EXACT_WAVES), wp = resident_waves(k_primary_shade<PT_MODEL_MAIN>, PT_EXACT_WAVES),
+        static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_MAIN>, PT_EXACT_WAVES, PT_PKT_LDS_BYTES), wp = resident_waves(k_primary_shade<PT_MODEL_MAIN>, PT_EXACT_WAVES),
                               wm = resident_waves(k_mirror_exact<PT_MODEL_MAIN>, PT_EXACT_WAVES);
-        hipLaunchKernelGGL(k_primary_search<PT_MODEL_MAIN>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_RING64_LDS_BYTES, s, PA);
+        hipLaunchKernelGGL(k_primary_search<PT_MODEL_MAIN>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_PKT_LDS_BYTES, s, PA);
         hipLaunchKernelGGL(k_primary_shade<PT_MODEL_MAIN>, dim3(blocks < wp ? blocks : wp), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         if (S.any_mirror) hipLaunchKernelGGL(k_mirror_exact<PT_MODEL_MAIN>, dim3(blocks < wm ? blocks : wm), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         hipLaunchKernelGGL(k_primary_combine<PT_MODEL_MAIN>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb, V.part, V.n_parts);
     } else {
-        static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_OMP>, PT_EXACT_WAVES), wm = resident_waves(k_mirror_exact<PT_MODEL_OMP>, PT_EXACT_WAVES);
+        static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_OMP>, PT_EXACT_WAVES, PT_PKT_LDS_BYTES), wm = resident_waves(k_mirror_exact<PT_MODEL_OMP>, PT_EXACT_WAVES);
         const size_t slots = P * (V.rb ? 9 : 1);
-        hipLaunchKernelGGL(k_primary_search<PT_MODEL_OMP>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_RING64_LDS_BYTES, s, PA);
+        hipLaunchKernelGGL(k_primary_search<PT_MODEL_OMP>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_PKT_LDS_BYTES, s, PA);
         const size_t sblocks = (slots + 255) / 256;
         hipLaunchKernelGGL(k_primary_shade_omp, dim3((unsigned)(sblocks < 2048 ? sblocks : 2048)), dim3(256), 0, s, S, V, F, B);
         // the listed sub-rays: few, so a grid of one wave per SIMD-quarter of the chip is plenty (the list's length is on the device)

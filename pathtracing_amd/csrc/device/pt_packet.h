@@ -13,6 +13,7 @@
 #include "pt_exact.h"
 
 #define PT_PKT_LDS 8                       // stack entries whose per-lane numbers live in LDS; deeper ones in device memory
+#define PT_PKT_LDS_BYTES (2 * PT_PKT_LDS * 64 * 8)   // shared memory of a block of the search kernel
 #define PT_PKT_CULL_MIN 1                  // lists shorter than this are tested without the packet test
 #ifndef PT_PKT_PRE_TRI
 #define PT_PKT_PRE_TRI 0                   // the next triangle of a list is fetched while the current one is tested

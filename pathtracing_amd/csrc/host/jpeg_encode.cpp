@@ -83,13 +83,16 @@ struct BitWriter {
 
 // Forward 8x8 DCT (separable, double precision: a frame is 4 096 blocks, speed is no concern) of level-shifted samples.
 void fdct(const float *in, float *out) {
-    static double c[8][8];
-    static bool init = false;
-    if (!init) {
+    // filled by the initialiser of a function-local static: once, and complete before any thread reads it (frames are
+    // written from several threads)
+    struct Table { double c[8][8]; };
+    static const Table table = [] {
+        Table t;
         for (int u = 0; u < 8; u++)
-            for (int x = 0; x < 8; x++) c[u][x] = (u == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
-        init = true;
-    }
+            for (int x = 0; x < 8; x++) t.c[u][x] = (u == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
+        return t;
+    }();
+    const double (&c)[8][8] = table.c;
     double tmp[64];
     for (int y = 0; y < 8; y++)
         for (int u = 0; u < 8; u++) {

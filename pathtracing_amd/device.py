@@ -30,7 +30,8 @@ class PtAov(C.Structure):
 class PtStats(C.Structure):
     _fields_ = [("primary", C.c_uint64), ("shadow", C.c_uint64), ("mirror", C.c_uint64), ("gi", C.c_uint64),
                 ("omp_retrace", C.c_uint64), ("ms_total", C.c_double), ("ms_gi_trace", C.c_double),
-                ("gi_trace_launches", C.c_uint64), ("gi_nodes_visited", C.c_uint64), ("gi_tris_tested", C.c_uint64)]
+                ("gi_trace_launches", C.c_uint64), ("gi_nodes_visited", C.c_uint64), ("gi_tris_tested", C.c_uint64),
+                ("ms_primary", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

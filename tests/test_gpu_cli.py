@@ -186,6 +186,31 @@ def test_bench_with_two_ranks_started_by_itself(cbox):
     assert abs(many[0]["views_per_s"] * many[0]["ms_per_step"] * 1e-3 - 6.0) < 0.01
 
 
+def test_a_view_that_fails_gets_a_second_attempt_on_another_worker(cbox, monkeypatch):
+    """A view whose render fails on one worker of pt_render_views is rendered again by a worker that is in order; the frames
+    and ray counts are those of the undisturbed job.  With a single worker there is nobody to take it: the call fails and
+    names the view's error."""
+    hs, ds = cbox
+    cams = host.views_from_path(os.path.join(ROOT, "scenes", "paths", "cboxpath.txt"), hs.camera()["zoom"])[:9]
+    kw = dict(gi=True, rb=True, spp=4, size=64, model=device.MODEL_OMP, gi_precision=device.GI_F32_FAST)
+    monkeypatch.delenv("PT_TUNE_REPLICAS", raising=False)
+    monkeypatch.delenv("PT_TUNE_FAIL_VIEW", raising=False)
+    monkeypatch.setenv("PT_TUNE_WORKERS", "3")
+    good, st0 = ds.render_views(cams, view0=0, view_stride=1, **kw)
+    for bad in ("0", "4", "8"):
+        monkeypatch.setenv("PT_TUNE_FAIL_VIEW", bad)
+        frames, st = ds.render_views(cams, view0=0, view_stride=1, **kw)
+        assert np.array_equal(good, frames), bad
+        for k in ("primary", "gi", "mirror", "shadow", "omp_retrace"):
+            assert st0[k] == st[k], (bad, k)
+    monkeypatch.setenv("PT_TUNE_WORKERS", "1")
+    with pytest.raises(device.DeviceError, match="injected failure"):
+        ds.render_views(cams, view0=0, view_stride=1, **kw)
+    monkeypatch.delenv("PT_TUNE_FAIL_VIEW")
+    again, _ = ds.render_views(cams, view0=0, view_stride=1, **kw)          # the scene is as usable as before
+    assert np.array_equal(good, again)
+
+
 def test_view_loop_over_several_workers_gives_the_same_frames(tmp_path, cbox, monkeypatch):
     """pt_render_views hands the views to worker threads: one copy of the scene per device, and on every device up to
     four workers that share that copy (several small views in flight fill the GPU better than one).
@@ -235,7 +260,7 @@ def test_view_loop_over_several_workers_gives_the_same_frames(tmp_path, cbox, mo
 def test_scene_slab_round_trip(cbox):
     """A scene's device data as one position-independent block: exported to host memory and to device memory, a scene
     made from either renders the same frame as the original (nothing is prepared again: the fp32 tree travels inside);
-    a block with a damaged header is refused."""
+    a block with a damaged header, or with a bit flipped anywhere in its arrays, is refused."""
     import ctypes as C
     hs, ds = cbox
     c = hs.camera()
@@ -273,6 +298,13 @@ def test_scene_slab_round_trip(cbox):
         device.DeviceScene(slab=(bad.ctypes.data, n, False))
     with pytest.raises(device.DeviceError):
         device.DeviceScene(slab=(buf.ctypes.data, n // 2, False))
+    # damage anywhere in the arrays -- a node link, a triangle offset, a texel -- is refused too (checksum over the body),
+    # not followed by the kernels
+    for at in (8192, n // 3, n // 2 + 5, n - 300):
+        bad = buf.copy()
+        bad[at] ^= 0x01
+        with pytest.raises(device.DeviceError, match="checksum"):
+            device.DeviceScene(slab=(bad.ctypes.data, n, False))
 
 
 def test_nccl_backend_exchanges_on_one_rank():
