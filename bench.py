@@ -18,6 +18,10 @@ roofline = the GI closest-hit kernel (the dominant kernel): algorithmic bytes
            per launch / mean launch duration (HIP events on the kernel's stream)
 cpu_baseline = the CPU oracle (a port of the reference's render path) timed on
            a bounded sample of the same workload, rank 0, N = 1 only.
+rm_rb16  = after the timed steps, a second leg timed by itself: the multi-view job at the reference's own settings
+           (`-gi -rb -rm`: mainOMP shading model, 16 samples, ray bundles; mainOMP.cpp:111-136,154-247) over every
+           view of the camera path, views dealt round-robin to the ranks, each rank's views handed to
+           pt_render_views in batches (several views in flight per GPU), frames gathered on rank 0.
 """
 import argparse
 import ctypes as C
@@ -89,7 +93,10 @@ def pmc_traffic(workload, rays_per_launch):
     if m is None or "FETCH_SIZE" not in m["values"] or "WRITE_SIZE" not in m["values"]:
         return None
     scale = rays_per_launch / m["rays_per_launch"]          # the launches the counters were collected on may differ in size
-    return round((2.0 * m["values"]["FETCH_SIZE"] + m["values"]["WRITE_SIZE"]) * 1024.0 * scale / 1e9, 2), m["source"]
+    gb = lambda f: round((f * m["values"]["FETCH_SIZE"] + m["values"]["WRITE_SIZE"]) * 1024.0 * scale / 1e9, 2)
+    # [0] with the guide's correction, [2] with FETCH_SIZE taken at face value: TCC_EA0_RDREQ x 64 B equals the uncorrected
+    # figure for this kernel's divergent 16-byte loads, so the truth lies between the two
+    return gb(2.0), m["source"], gb(1.0)
 
 
 def measure_load_rates():
@@ -128,8 +135,12 @@ def physical_roofline(workload, n_node, n_tri, kernel_mrays, ms_launch, rays_lau
         if "SQ_INSTS_VALU" in v and "GRBM_GUI_ACTIVE" in v:
             # instructions x 4 cycles (a wave64 instruction on a 16-lane SIMD) over the SIMD cycles of the launch; the raw figure
             # can pass 1 by a percent (an instruction whose upper or lower 32 lanes are all idle takes fewer cycles)
-            raw = v["SQ_INSTS_VALU"] * 4.0 / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
-            phys["valu_issue"], phys["valu_issue_raw"] = round(min(raw, 1.0), 3), round(raw, 3)
+            # (a model, not a counter: 4 cycles per instruction is the common case, not every case)
+            phys["valu_issue"] = round(v["SQ_INSTS_VALU"] * 4.0 / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 3)
+        if "SQ_THREAD_CYCLES_VALU" in v and "SQ_ACTIVE_INST_VALU" in v:
+            # lanes that do work per issued vector instruction: each lane of the traversal uses one or two of the three
+            # blocks (triangle test, quad step, leaf step) that the whole wave walks through on every turn
+            phys["valu_live_lanes"] = round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 3)
         tr = pmc_traffic(workload, rays_launch)
         if tr and ms_launch > 0:
             phys["hbm_side_gb_per_s"] = round(tr[0] / (ms_launch * 1e-3), 1)
@@ -141,14 +152,20 @@ def physical_roofline(workload, n_node, n_tri, kernel_mrays, ms_launch, rays_lau
         ceiling = 256 * 2.4e9 / (req * clocks) / 1e6           # the micro-benchmark normalises by the same 256 CUs x 2.4 GHz
         phys.update(clocks_per_request=round(clocks, 3), request_ceiling_mrays_per_s=round(ceiling, 1),
                     achieved_mrays_per_s=round(kernel_mrays, 1), request_model_frac=round(kernel_mrays / ceiling, 4))
-    # the fraction that counts: how busy the busiest of the two units that bound the kernel is (1 = that unit never idles)
+    # which of the two units that bound the kernel is busier, and the fraction that counts: when it is the vector ALUs, the
+    # share of their LANE-cycles that do work (issue x live lanes) -- a wave that issues on every cycle with 40 % of its
+    # lanes alive uses 40 % of the ALUs
     units = {k: phys[k] for k in ("ta_busy", "valu_issue") if k in phys}
     if units:
         top = max(units, key=units.get)
         phys["limiter"] = ("per-lane load requests through the L1 address path (TA), then VALU issue" if top == "ta_busy" else
                            "VALU issue, then per-lane load requests through the L1 address path (TA)")
-        phys["frac"] = units[top]
-        phys["frac_of"] = {"ta_busy": "L1 address path (TA) busy cycles / cycles", "valu_issue": "VALU issue cycles / SIMD cycles"}[top]
+        if top == "valu_issue" and "valu_live_lanes" in phys:
+            phys["frac"] = round(min(phys["valu_issue"], 1.0) * phys["valu_live_lanes"], 3)
+            phys["frac_of"] = "vector ALU lane-cycles that do work: VALU issue (capped at 1) x live lanes per instruction"
+        else:
+            phys["frac"] = units[top]
+            phys["frac_of"] = {"ta_busy": "L1 address path (TA) busy cycles / cycles", "valu_issue": "VALU issue cycles / SIMD cycles (model)"}[top]
     return phys
 
 
@@ -218,6 +235,79 @@ def launch_ranks(n):
     return child.wait()
 
 
+def oracle_sample(orc, po, view, view_index, model, rb, spp, size, seconds):
+    """The CPU oracle on a bounded sample of one view: every k-th image row, sized for about `seconds` of CPU work."""
+    cores = min(16, os.cpu_count() or 1)
+    okw = dict(eye=list(view.eye), angle=view.angle, zoom=view.zoom, model=po.MODEL_OMP if model == "omp" else po.MODEL_MAIN,
+               gi=True, rb=rb, spp=spp, rng=po.RNG_PHILOX, view=view_index, size=size, threads=cores, aov=False)
+    # one row per thread first, to size the sample
+    probe = orc.render(row0=size // (2 * cores), row_step=size // cores, nrows_limit=cores, **okw)
+    rows = int(min(size, max(cores, cores * round(seconds / max(probe["seconds"], 1e-3)))))
+    rows = max(cores, (rows // cores) * cores)
+    step_rows = max(1, size // rows)
+    r = orc.render(row0=step_rows // 2, row_step=step_rows, nrows_limit=rows, **okw)
+    crays = sum(v["searches"] for k, v in r["counts"].items() if k != "omp_retrace")
+    return {"value": round(crays / r["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "host_cpus_visible": os.cpu_count(),       # the whole machine; a one-GPU job's share of it is 16 threads
+            "views_per_s_extrapolated": round(rows / size / r["seconds"], 5),
+            "sample": f"{rows} of {size} image rows (every {step_rows}th) of one view at {spp} spp{' with ray bundles' if rb else ''}: "
+                      f"{crays} rays in {r['seconds']:.1f} s on {cores} threads"}
+
+
+def rm_rb16_leg(ds, cams, size, rank, world, dev, xdev, dist, backend):
+    """The multi-view job at the reference's settings, timed by itself: -gi -rb, mainOMP model, 16 samples
+    (mainOMP.cpp:117-118,132), every view of the path, view v on rank v % world, frames gathered on rank 0."""
+    import torch
+    from pathtracing_amd import device, multiview
+    opt = dict(gi=True, rb=True, model=device.MODEL_OMP, spp=16, gi_precision=device.GI_F32_FAST, size=size)
+    keys = ("primary", "shadow", "mirror", "gi", "ms_gi_trace", "ms_primary", "gi_trace_launches")
+    acc = dict.fromkeys(keys, 0.0)
+
+    def render_many(first, stride, count):
+        sel = cams[first: first + stride * count: stride]
+        frames, sd = ds.render_views([device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])) for c in sel],
+                                     view0=first, view_stride=stride, **opt)
+        for k in keys:
+            acc[k] += sd[k]
+        return frames.reshape(count, -1)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n = len(cams)
+    render_many(rank, world, min(8, len(range(rank, n, world))))           # warm-up: the view workers and their workspaces
+    for k in keys:
+        acc[k] = 0.0
+    got = [0]
+    sync()
+    t0 = time.perf_counter()
+    multiview.run_views(None, n, size * size * 3, xdev, dist if world > 1 else None,
+                        (lambda v, px: got.__setitem__(0, got[0] + 1)) if rank == 0 else None, batch=32, render_many=render_many)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt] + [acc[k] for k in keys], dtype=torch.float64, device=xdev)
+    if world > 1:
+        tmax = t[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        t[0] = tmax[0]
+    v = [float(x) for x in t.cpu()]
+    dt, tot = v[0], dict(zip(keys, v[1:]))
+    if rank != 0:
+        return None
+    assert got[0] == n, f"rank 0 holds {got[0]} of {n} frames"
+    rays = tot["primary"] + tot["shadow"] + tot["mirror"] + tot["gi"]
+    return {"config": "-gi -rb -rm: mainOMP shading model, 16 spp, 3x3 ray bundles at +-0.1 px, 512x512, every view of the path",
+            "n_views": n, "views_per_s": round(n / dt, 2), "ms_per_view": round(dt / n * 1e3, 4), "seconds": round(dt, 4),
+            "scaling": "strong (the views of the path are shared by all ranks, view v on rank v % N)",
+            "mrays_per_s": round(rays / dt / 1e6, 1),
+            # device time per view of the two passes that make up a view (several views are in flight per GPU, so these overlap in wall time)
+            "primary_ms": round(tot["ms_primary"] / n, 4), "closest_ms": round(tot["ms_gi_trace"] / n, 4),
+            "frames_on_rank0": got[0], "backend": backend if world > 1 else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,6 +320,7 @@ def main():
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="views each GPU renders per step, handed to the library in one call (it keeps several small views in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rm-leg", action="store_true", help="skip the second leg (the -gi -rb -rm job at the reference's settings)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path with every rank on GPU 0 and the exchanges staged through host memory")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -284,8 +375,27 @@ def main():
         hs, st, views = load_host_scene(a.workload)
         ds = device.DeviceScene(hs.desc())                    # the one place the scene is prepared (fp32 tree included)
         cams = np.array([[*v.eye, v.angle, v.zoom] for v in views])
+    scene_broadcast = ranks = None
     if world > 1:
+        # who is here: one line per rank, and -- with RCCL -- a check that the ranks really sit on different devices
+        props = torch.cuda.get_device_properties(gpu)
+        me = {"rank": rank, "local_rank": local_rank, "device": gpu, "device_name": props.name,
+              "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xFF,
+                                                getattr(props, "pci_device_id", 0)),
+              "uuid": str(getattr(props, "uuid", ""))}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        if a.backend == "nccl":
+            ids = [(r["pci_bus_id"], r["uuid"]) for r in ranks]
+            assert len(set(ids)) == world, f"ranks share a device: {ids}"
+        dist.barrier()
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
         ds = multiview.broadcast_scene(ds, xdev, dist)        # the scene's device data travels over xGMI once, GPU to GPU
+        torch.cuda.synchronize()
+        dist.barrier()
+        scene_broadcast = {"bytes": int(ds.slab_size()), "ms": round((time.perf_counter() - t_b) * 1e3, 2),
+                           "what": "slab exported device to device, one broadcast, every other rank's scene made from its copy (body checksum included)"}
         cams = multiview.broadcast_cameras(cams if rank == 0 else None, xdev, dist)
     scene_seconds = time.time() - t_scene
     views = [device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])) for c in cams]
@@ -345,13 +455,18 @@ def main():
     dt = time.perf_counter() - t0
 
     rays_local = stats.primary + stats.shadow + stats.mirror + stats.gi
-    agg = torch.tensor([dt, float(rays_local), float(stats.gi)], dtype=torch.float64, device=xdev)
+    agg = torch.tensor([dt, float(rays_local), float(stats.gi), float(stats.primary), float(stats.mirror), float(stats.shadow)],
+                       dtype=torch.float64, device=xdev)
     if world > 1:
         tmax = agg[0:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg[1:], op=dist.ReduceOp.SUM)
         agg[0] = tmax[0]
-    dt_max, rays_total, gi_total = (float(x) for x in agg.cpu())
+    dt_max, rays_total, gi_total, n_primary, n_mirror, n_shadow = (float(x) for x in agg.cpu())
+    by_class = {"primary": n_primary, "mirror": n_mirror, "shadow": n_shadow, "gi": gi_total}
+
+    # ---- second leg: the multi-view job at the reference's own settings ----
+    rm = None if a.no_rm_leg else rm_rb16_leg(ds, cams, size, rank, world, dev, xdev, dist, a.backend)
 
     if rank == 0:
         # ---- algorithmic bytes per ray of the dominant kernel: a counting run (untimed) ----
@@ -387,11 +502,17 @@ def main():
                                                        max(stats.gi_trace_launches + warm.gi_trace_launches, 1), 4)}
         tr = pmc_traffic(a.workload, rays_launch)
         if tr:
-            roofline["traffic"], roofline["traffic_source"] = tr
+            roofline["traffic"], roofline["traffic_source"], roofline["traffic_fetch_at_face_value"] = tr
             roofline["traffic_stale"] = pmc_means(a.workload)["kernel_source_hash"] != kernel_source_hash()
             roofline["algorithmic_gb_per_launch"] = round(bytes_per_ray * rays_launch / 1e9, 2)
+            # what the memory side really moves (counters of the committed collection, scaled to this run's launches):
+            # the kernel's HBM roofline position as a physicist would state it -- `achieved` / `frac` above are the
+            # algorithmic bytes, most of which the caches serve
+            if ms_launch > 0:
+                roofline["hbm_measured_gb_per_s"] = round(tr[0] / (ms_launch * 1e-3), 1)
+                roofline["hbm_measured_frac"] = round(tr[0] / (ms_launch * 1e-3) / HBM_PEAK_GBS, 4)
         roofline["physical"] = physical_roofline(a.workload, n_node, n_tri, kernel_mrays, ms_launch, rays_launch) if world == 1 else None
-        cpu = None
+        cpu = cpu_rm = None
         if world == 1 and not a.no_cpu_baseline:
             from oracle import ptoracle as po
             packed = WORKLOADS[a.workload][0]
@@ -405,21 +526,9 @@ def main():
             orc = po.OracleScene(packed_path)
             if tmp:
                 os.remove(tmp)
-            cores = min(16, os.cpu_count() or 1)
-            v0 = views[a.warmup % nviews]
-            okw = dict(eye=list(v0.eye), angle=v0.angle, zoom=v0.zoom, model=po.MODEL_OMP if a.model == "omp" else po.MODEL_MAIN,
-                       gi=True, rb=a.rb, spp=a.spp, rng=po.RNG_PHILOX, view=a.warmup % nviews, size=size, threads=cores, aov=False)
-            # one row per thread first, to size the sample for about --cpu-seconds of CPU work
-            probe = orc.render(row0=size // (2 * cores), row_step=size // cores, nrows_limit=cores, **okw)
-            rows = int(min(size, max(cores, cores * round(a.cpu_seconds / max(probe["seconds"], 1e-3)))))
-            rows = max(cores, (rows // cores) * cores)
-            step_rows = max(1, size // rows)
-            r = orc.render(row0=step_rows // 2, row_step=step_rows, nrows_limit=rows, **okw)
-            crays = sum(v["searches"] for k, v in r["counts"].items() if k != "omp_retrace")
-            cpu = {"value": round(crays / r["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                   "host_cpus_visible": os.cpu_count(),       # the whole machine; a one-GPU job's share of it is 16 threads
-                   "sample": f"{rows} of 512 image rows (every {step_rows}th) of one view at the same spp: "
-                             f"{crays} rays in {r['seconds']:.1f} s on {cores} threads"}
+            cpu = oracle_sample(orc, po, views[a.warmup % nviews], a.warmup % nviews, a.model, a.rb, a.spp, size, a.cpu_seconds)
+            if not a.no_rm_leg:
+                cpu_rm = oracle_sample(orc, po, views[0], 0, "omp", True, 16, size, min(a.cpu_seconds, 8.0))
 
         out = {
             "metric": "Mrays/s (all ray classes of -gi views; GI sample rays dominate)",
@@ -438,10 +547,17 @@ def main():
                        "device_tree": ds.info()},
             "views_per_s": round(a.steps * world * B / dt_max, 3),
             "gi_mrays_per_s": round(gi_total / dt_max / 1e6, 1),
+            # rays of each class of all ranks over the same wall time (the classes are traced one after the other, not side by side)
+            "mrays_per_s_by_class": {k: round(v / dt_max / 1e6, 2) for k, v in by_class.items()},
+            "rays_by_class": {k: int(v) for k, v in by_class.items()},
+            "backend": a.backend if world > 1 else None, "ranks": ranks, "scene_broadcast": scene_broadcast,
             "scene_setup_s": round(scene_seconds, 2),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "rm_rb16": rm,
         }
+        if rm is not None:
+            rm["cpu_baseline"] = cpu_rm
         print(json.dumps(out), flush=True)
     ds.close()
     if world > 1:

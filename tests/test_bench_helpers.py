@@ -10,9 +10,9 @@ def test_pmc_traffic_reads_the_committed_counter_summaries():
     for workload in ("atrium", "car"):
         got = bench.pmc_traffic(workload, 16777216)
         assert got is not None, workload
-        gb, source = got
+        gb, source, gb_face = got
         assert source.startswith("profiles/") and os.path.exists(os.path.join(ROOT, source))
-        assert 0.1 < gb < 100.0
+        assert 0.1 < gb_face <= gb < 100.0          # FETCH_SIZE with the guide's correction, and at face value
     assert bench.pmc_traffic("no-such-workload", 1) is None
     half = bench.pmc_traffic("atrium", 8388608)[0]
     assert abs(half - bench.pmc_traffic("atrium", 16777216)[0] / 2) < 0.02
@@ -23,11 +23,16 @@ def test_counter_collections_carry_the_kernel_source_digest():
     traffic and hit rates as stale when the sources have changed since."""
     import bench
     m = bench.pmc_means("atrium")
-    assert m["source"].startswith("profiles/r02/") and m["kernel_source_hash"] and m["rays_per_launch"] > 6e7
+    assert m["source"].startswith("profiles/r0") and m["kernel_source_hash"] and m["rays_per_launch"] > 6e7
     assert len(bench.kernel_source_hash()) == 16
     p = bench.physical_roofline("atrium", 63.6, 15.25, 4450.0, 15.0, 67108800)
     assert p["counters_stale"] == (m["kernel_source_hash"] != bench.kernel_source_hash())
-    assert 0.5 < p["frac"] <= 1.0 and p["frac"] == max(p["ta_busy"], p["valu_issue"])
+    # the busier unit decides; for the vector ALUs the fraction is lane-weighted (issue x live lanes per instruction)
+    assert 0.2 < p["frac"] <= 1.0 and 0.2 < p["valu_live_lanes"] <= 1.0
+    if p["valu_issue"] >= p["ta_busy"]:
+        assert abs(p["frac"] - min(p["valu_issue"], 1.0) * p["valu_live_lanes"]) < 2e-3
+    else:
+        assert p["frac"] == p["ta_busy"]
     assert 0.05 < p["hbm_side_frac_of_peak"] < 0.5          # the kernel is far from HBM-bound
 
 

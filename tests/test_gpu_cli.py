@@ -176,6 +176,17 @@ def test_bench_with_two_ranks_started_by_itself(cbox):
     # weak scaling: every rank renders the same cameras, so the job traced twice the rays
     rays = lambda j: j["value"] * 1e6 * j["ms_per_step"] * 1e-3 * j["steps"]
     assert abs(rays(two) / rays(one) - 2.0) < 0.02
+    # who took part and what the start of the job cost: one entry per rank, the backend, the scene broadcast timed by itself
+    assert one["ranks"] is None and one["backend"] is None and one["scene_broadcast"] is None
+    assert [r["rank"] for r in two["ranks"]] == [0, 1] and all(r["device_name"] and r["pci_bus_id"] for r in two["ranks"])
+    assert two["backend"] == "gloo" and two["scene_broadcast"]["bytes"] > 1 << 20 and two["scene_broadcast"]["ms"] > 0
+    # ray classes, and the second leg: the -gi -rb -rm job at the reference's settings over every view of the path
+    for j in (one, two):
+        c = j["mrays_per_s_by_class"]
+        assert set(c) == {"primary", "mirror", "shadow", "gi"} and abs(sum(c.values()) - j["value"]) < 0.01 * j["value"] + 0.1
+        rm = j["rm_rb16"]
+        assert rm["n_views"] == rm["frames_on_rank0"] == 320 and rm["views_per_s"] > 0 and rm["primary_ms"] > 0 and rm["closest_ms"] > 0
+        assert abs(rm["views_per_s"] * rm["ms_per_view"] * 1e-3 - 1.0) < 0.01
     # several views per rank and step, handed to the library in one call (which keeps them in flight together)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "cbox", "--spp", "16",
                         "--steps", "2", "--warmup", "1", "--views-per-step", "3", "--no-cpu-baseline"], cwd=ROOT, env=env,

@@ -7,7 +7,7 @@ OUT=gpurun_out/ab_$TAG.txt
 mkdir -p gpurun_out
 : > "$OUT"
 for cfg in "$@"; do
-  line=$(env $cfg timeout -k 10 240 python3 -u bench.py --no-cpu-baseline $ARGS 2>/dev/null | grep '^{' | tail -1) || { echo "$cfg: failed" >> "$OUT"; exit 1; }
+  line=$(env $cfg timeout -k 10 240 python3 -u bench.py --no-cpu-baseline --no-rm-leg $ARGS 2>/dev/null | grep '^{' | tail -1) || { echo "$cfg: failed" >> "$OUT"; exit 1; }
   python3 - "$cfg" "$line" >> "$OUT" <<'PY'
 import json, sys
 j = json.loads(sys.argv[2])

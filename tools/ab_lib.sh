@@ -7,7 +7,7 @@ ARGS=$1; shift
 OUT=gpurun_out/ab_lib.txt; mkdir -p gpurun_out; : > $OUT
 cp pathtracing_amd/libptamd.so /tmp/libptamd_base.so
 one() {
-  line=$(timeout -k 10 240 python3 -u bench.py --no-cpu-baseline $ARGS 2>/dev/null | grep '^{' | tail -n 1) || { echo "$1: failed" >> $OUT; return 1; }
+  line=$(timeout -k 10 240 python3 -u bench.py --no-cpu-baseline --no-rm-leg $ARGS 2>/dev/null | grep '^{' | tail -n 1) || { echo "$1: failed" >> $OUT; return 1; }
   python3 -c "
 import json, sys
 j = json.loads(sys.argv[2])

@@ -7,7 +7,7 @@ TAG=${2:-$W}
 OUT=gpurun_out/profile_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="bench.py --workload $W --no-cpu-baseline ${PROFILE_ARGS:-}"      # the default run of bench.py minus the CPU leg (PROFILE_ARGS adds options)
+ARGS="bench.py --workload $W --no-cpu-baseline --no-rm-leg ${PROFILE_ARGS:-}"      # the default run of bench.py minus the CPU leg (PROFILE_ARGS adds options)
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k -- python3 $ARGS > "$OUT/trace.log" 2>&1 || { echo "kernel trace failed"; exit 1; }
 grep "^{" "$OUT/trace.log" > "$OUT/bench_under_trace.json"
 run() {

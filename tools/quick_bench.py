@@ -8,7 +8,7 @@ import sys
 args = sys.argv[1:] or ["car", "atrium"]
 for w in args:
     out = subprocess.run([sys.executable, "bench.py", "--workload", w, "--steps", "3", "--warmup", "1", "--spp", "64",
-                          "--no-cpu-baseline"] + os.environ.get("QB_ARGS", "").split(), capture_output=True, text=True)
+                          "--no-cpu-baseline --no-rm-leg"] + os.environ.get("QB_ARGS", "").split(), capture_output=True, text=True)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(w, "FAILED", out.stdout[-2000:], out.stderr[-2000:])

@@ -6,7 +6,7 @@ TAG=$1; shift
 OUT=gpurun_out/tl_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o k -- python3 bench.py --no-cpu-baseline "$@" > "$OUT/trace.log" 2>&1 || { echo "kernel trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
+timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o k -- python3 bench.py --no-cpu-baseline --no-rm-leg "$@" > "$OUT/trace.log" 2>&1 || { echo "kernel trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 grep "^{" "$OUT/trace.log" > "$OUT/bench.json"
 python3 - "$OUT" <<'PY' | tee "$OUT/timeline.txt"
 import csv, glob, sys, os, json
