@@ -44,7 +44,25 @@ tools/ta_rate: tools/ta_rate.hip
 oracle/libptoracle.so: oracle/pt_oracle.c
 	$(MAKE) -C oracle
 
+# Sanitizer builds of the CPU code (host library, oracle; the test helpers follow PT_SANITIZE=1 themselves) and the CPU
+# tests that feed them untrusted bytes (texture decoders, packed scenes), the kd build and the search rules, run under them.
+# The Python interpreter is not instrumented, so the AddressSanitizer runtime is put in front of whatever is preloaded already.
+SAN      := -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -g
+ASAN_DIR := build/asan
+asan: $(ASAN_DIR)/libpthost.so $(ASAN_DIR)/libptoracle.so
+$(ASAN_DIR)/libpthost.so: $(HOSTSRC) $(PKG)/csrc/host/scene.hpp include/pathtracing_host.h include/pathtracing_amd.h
+	mkdir -p $(ASAN_DIR)
+	$(CXX) $(CXXFLAGS) -O1 $(SAN) -shared -o $@ $(HOSTSRC)
+$(ASAN_DIR)/libptoracle.so: oracle/pt_oracle.c
+	mkdir -p $(ASAN_DIR)
+	$(CC) -O1 -std=gnu11 -fPIC -shared -fopenmp -ffp-contract=off $(SAN) -o $@ oracle/pt_oracle.c -lm
+ASAN_TESTS ?= tests/test_host.py tests/test_refine_host.py tests/test_research_rule.py tests/test_packet_rule.py tests/test_oracle_pins.py tests/test_golden.py
+asan-test: asan
+	PT_SANITIZE=1 ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+	LD_PRELOAD="$$($(CC) -print-file-name=libasan.so):$$LD_PRELOAD" python3 -m pytest $(ASAN_TESTS) -q -m "not gpu" -p no:cacheprovider
+
 clean:
+	rm -rf build
 	rm -f $(DEVOBJ) $(PKG)/libpthost.so $(PKG)/libptamd.so $(PKG)/ptmain oracle/libptoracle.so tools/ta_rate
 
-.PHONY: all host device cli oracle tools clean
+.PHONY: all host device cli oracle tools clean asan asan-test

@@ -41,6 +41,8 @@ def lib():
     global _lib
     if _lib is None:
         path = os.path.join(_DIR, "libptoracle.so")
+        if os.environ.get("PT_SANITIZE") == "1":         # the sanitizer build of `make asan`
+            path = os.path.join(os.path.dirname(_DIR), "build", "asan", "libptoracle.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -135,7 +135,7 @@ void idct_block(const int32_t *in, uint8_t *out, int stride) {
             int64_t z2 = s[2], z3 = s[6];
             int64_t z1 = (z2 + z3) * F0541;
             int64_t t2 = z1 - z3 * F1847, t3 = z1 + z2 * F0765;
-            int64_t t0 = (s[0] + s[4]) << CB, t1 = (s[0] - s[4]) << CB;
+            int64_t t0 = (s[0] + s[4]) * ((int64_t)1 << CB), t1 = (s[0] - s[4]) * ((int64_t)1 << CB);   // a product: the sums may be negative
             int64_t t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
             int64_t o0 = s[7], o1 = s[5], o2 = s[3], o3 = s[1];
             z1 = o0 + o3; z2 = o1 + o2; z3 = o0 + o2;

@@ -54,6 +54,8 @@ def lib():
     global _lib
     if _lib is None:
         path = os.path.join(_DIR, "libpthost.so")
+        if os.environ.get("PT_SANITIZE") == "1":         # the sanitizer build of `make asan` (CPU tests only)
+            path = os.path.join(os.path.dirname(_DIR), "build", "asan", "libpthost.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make host` (or __graft_entry__.build())")
         L = C.CDLL(path)

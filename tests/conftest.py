@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def sanitizer_flags():
+    """Extra compiler flags for the C / C++ helpers that tests build: with PT_SANITIZE=1 (`make asan-test`) they are
+    instrumented like the libraries they are linked with."""
+    if os.environ.get("PT_SANITIZE") == "1":
+        return ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+    return []
+
+
 _packed_here = {}
 
 

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, scene_path
+from conftest import ROOT, sanitizer_flags, scene_path
 
 NAMES = "packets rays node_visits lists list_entries survivors lane_tests any_pass pushes pops max_depth ref_nodes ref_tris loose kept64".split()
 
@@ -21,7 +21,7 @@ NAMES = "packets rays node_visits lists list_entries survivors lane_tests any_pa
 def checker(tmp_path_factory):
     so = tmp_path_factory.mktemp("packet") / "packet_check.so"
     subprocess.run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-o", str(so),
-                    os.path.join(ROOT, "tests", "packet_check.c"), "-lm"], check=True)
+                    os.path.join(ROOT, "tests", "packet_check.c"), "-lm"] + sanitizer_flags(), check=True)
     L = C.CDLL(str(so))
     L.orc_scene_load.restype = C.c_void_p
     L.orc_scene_load.argtypes = [C.c_char_p]

@@ -7,14 +7,14 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, scene_path
+from conftest import ROOT, sanitizer_flags, scene_path
 
 
 @pytest.fixture(scope="module")
 def checker(tmp_path_factory):
     so = tmp_path_factory.mktemp("research") / "research_check.so"
     subprocess.run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-o", str(so),
-                    os.path.join(ROOT, "tests", "research_check.c"), "-lm"], check=True)
+                    os.path.join(ROOT, "tests", "research_check.c"), "-lm"] + sanitizer_flags(), check=True)
     L = C.CDLL(str(so))
     L.orc_scene_load.restype = C.c_void_p
     L.orc_scene_load.argtypes = [C.c_char_p]
