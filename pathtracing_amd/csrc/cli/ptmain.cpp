@@ -21,7 +21,9 @@
 // <SCENE>4096ssp and <SCENE>dif, named <scene><view>.ppm: 4 spp, 4096 spp and the
 // pass without -gi of mainOMP.cpp:263-270; --noisy-spp / --converged-spp change
 // the two counts), --format ppm|jpg (frame files; jpg is what the reference's data
-// sets are, written with cv::imwrite's default quality 95).
+// sets are, written with cv::imwrite's default quality 95), --resume (with -rm: frame
+// files that are already there, whole, are kept and their views not rendered again;
+// the reference restarts at view 0 and only shows its frames, mainOMP.cpp:242).
 #include <cctype>
 #include <iostream>
 #include <sstream>
@@ -46,7 +48,7 @@ static int die(const char *what, const char *msg) {
 }
 
 int main(int argc, char **argv) {
-    bool gi = false, rb = false, rm = false, exact_gi = false, from_stdin = false, all_gpus = false;
+    bool gi = false, rb = false, rm = false, exact_gi = false, from_stdin = false, all_gpus = false, resume = false;
     std::string scene, model_s, out = ".", keys, dataset, format = "ppm";
     int spp = 0, size = 0, max_views = -1, dev = 0, noisy_spp = 4, converged_spp = 4096;
     for (int i = 1; i < argc; i++) {
@@ -58,6 +60,7 @@ int main(int argc, char **argv) {
         if (a == "-gi") gi = true;
         else if (a == "-rb") rb = true;
         else if (a == "-rm") rm = true;
+        else if (a == "--resume") resume = true;
         else if (a == "-pp") { std::fprintf(stderr, "ptmain: -pp (Keras post-processing) is not part of this build\n"); return 2; }
         else if (a == "--model") model_s = val("--model");
         else if (a == "--spp") spp = std::atoi(val("--spp"));
@@ -118,7 +121,26 @@ int main(int argc, char **argv) {
     auto write_frame = [&](const std::string &file, const uint8_t *bgr) -> int {
         return format == "jpg" ? pth_write_jpeg(file.c_str(), bgr, n, n, 95) : pth_write_ppm(file.c_str(), bgr, n, n);
     };
+    // --resume: is this frame file already there, whole?  A PPM of this size has one length; a JPEG ends with its end marker.
+    auto frame_file_complete = [&](const std::string &file) -> bool {
+        FILE *f = std::fopen(file.c_str(), "rb");
+        if (!f) return false;
+        bool ok = false;
+        if (std::fseek(f, 0, SEEK_END) == 0) {
+            const long len = std::ftell(f);
+            if (format == "jpg") {
+                unsigned char tail[2] = {0, 0};
+                ok = len > 4 && std::fseek(f, -2, SEEK_END) == 0 && std::fread(tail, 1, 2, f) == 2 && tail[0] == 0xFF && tail[1] == 0xD9;
+            } else {
+                char hdr[64];
+                ok = len == (long)std::snprintf(hdr, sizeof hdr, "P6\n%d %d\n255\n", n, n) + (long)frame.size();
+            }
+        }
+        std::fclose(f);
+        return ok;
+    };
     auto render_one = [&](const PtCamera &cam, uint32_t view, const std::string &file) -> int {
+        if (resume && frame_file_complete(file)) { std::printf("  kept %s\n", file.c_str()); return 0; }
         opt.view = view;
         PtStats st{};
         auto t0 = std::chrono::high_resolution_clock::now();
@@ -156,8 +178,13 @@ int main(int argc, char **argv) {
             int write_failed = 0;
             PtStats st{};
             auto t0 = std::chrono::high_resolution_clock::now();
-            size_t turn = 0;
-            for (size_t v0 = 0; v0 < total; v0 += batch, turn ^= 1) {
+            size_t turn = 0, start = 0;
+            if (resume) {                                       // the job goes on at the first view whose file is not whole
+                auto file_of = [&](size_t v) { char name[64]; std::snprintf(name, sizeof name, "/%s%zu", scene.c_str(), v); return out + name + ext; };
+                while (start < total && frame_file_complete(file_of(start))) start++;
+                std::printf("Resuming at view %zu of %zu\n", start, total);
+            }
+            for (size_t v0 = start; v0 < total; v0 += batch, turn ^= 1) {
                 const size_t nb = total - v0 < batch ? total - v0 : batch;
                 auto tb = std::chrono::high_resolution_clock::now();
                 uint8_t *buf = frames[turn].data();
@@ -180,8 +207,8 @@ int main(int argc, char **argv) {
             if (write_failed) return die("write", "a frame file could not be written");
             std::chrono::duration<double> el = std::chrono::high_resolution_clock::now() - t0;
             const unsigned long long rays = st.primary + st.shadow + st.mirror + st.gi;
-            std::printf("%zu views on %d GPU(s) in %.3f s: %.2f views/s, %.1f Mrays/s\n", total, pt_device_count(), el.count(),
-                        (double)total / el.count(), (double)rays / el.count() * 1e-6);
+            std::printf("%zu views on %d GPU(s) in %.3f s: %.2f views/s, %.1f Mrays/s\n", total - start, pt_device_count(), el.count(),
+                        (double)(total - start) / el.count(), (double)rays / el.count() * 1e-6);
             total = 0;                                          // nothing left for the loop below
         }
         for (size_t v = 0; v < total; v++) {

@@ -1,6 +1,6 @@
 """The multi-view job of the reference (`mpirun ./mainOMP <scene> -gi [-rb] -rm`, mainOMP.cpp:225-247,328-354) on GPUs.
 
-    python -m pathtracing_amd.rm <scene> [-gi] [-rb] [--model omp|main] [--spp N] [--size N] [--views N] [--out DIR] [--split-rows]
+    python -m pathtracing_amd.rm <scene> [-gi] [-rb] [--model omp|main] [--spp N] [--size N] [--views N] [--out DIR] [--split-rows] [--resume]
     python -m torch.distributed.run --nproc-per-node N -m pathtracing_amd.rm <scene> -gi ...
 
 One process per GPU; rank 0 reads the scene, builds the trees and uploads it, its device data travels to the other ranks
@@ -8,6 +8,8 @@ in one broadcast (RCCL, GPU to GPU, when the backend is nccl), view v of scenes/
 v % N, and rank 0 collects the frames and writes <out>/<scene><v>.ppm.  Frames do not depend on N.
 With --split-rows every view is rendered by all N GPUs together instead, each the 8-row bands b with b % N == rank
 (the reference's own dealing of rows to its workers, mainOMP.cpp:169-174): same frames, shorter time to each frame.
+With --resume the job starts at the first view whose file is missing or incomplete (the reference restarts from view 0
+and only shows its frames: "change to imwrite", mainOMP.cpp:242); frames do not depend on where a job started.
 """
 import argparse
 import os
@@ -33,6 +35,7 @@ def main(argv=None):
     ap.add_argument("--split-rows", action="store_true", help="all GPUs share every view (bands of 8 rows) instead of one view each")
     ap.add_argument("--exact-gi", action="store_true", help="fp64 GI rays (bit-identical to the CPU oracle)")
     ap.add_argument("--writers", type=int, default=4, help="threads of rank 0 that write the frame files")
+    ap.add_argument("--resume", action="store_true", help="skip the views at the start of the path whose files are already complete")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: every rank on GPU 0, exchanges staged through host memory (rehearsal on a one-GPU box)")
     a = ap.parse_args(argv)
@@ -54,6 +57,7 @@ def main(argv=None):
     device.init(gpu)
 
     ds = cams = None
+    first_view = 0
     if rank == 0:
         sdir = os.path.join(a.root, "scenes", a.scene)
         hs = (host.HostScene.from_dir(sdir) if os.path.exists(os.path.join(sdir, "master.txt"))
@@ -66,9 +70,19 @@ def main(argv=None):
         if a.views >= 0:
             cams = cams[: a.views]
         ds = device.DeviceScene(hs.desc())                    # the only rank that prepares the scene (fp32 tree included)
+        if a.resume:
+            # a PPM frame of this size has one length; the first view whose file has another (or none) is where the job goes on
+            want = len(b"P6\n%d %d\n255\n" % (a.size, a.size)) + a.size * a.size * 3
+            while first_view < len(cams) and os.path.exists(os.path.join(a.out, f"{a.scene}{first_view}.ppm")) and \
+                    os.path.getsize(os.path.join(a.out, f"{a.scene}{first_view}.ppm")) == want:
+                first_view += 1
+            print(f"Resuming at view {first_view} of {len(cams)}")
+            cams = np.concatenate([cams[first_view:], np.full((1, 5), float(first_view))])     # the offset travels with the cameras
     if world > 1:
         ds = multiview.broadcast_scene(ds, xdev, dist)        # its device data, GPU to GPU
         cams = multiview.broadcast_cameras(cams, xdev, dist)
+    if a.resume:
+        first_view, cams = int(cams[-1][0]), cams[:-1]
     n = a.size
     frame = torch.empty(n * n * 3, dtype=torch.uint8, device=dev)
     opt = dict(gi=a.gi, rb=a.rb, model=device.MODEL_OMP if a.model == "omp" else device.MODEL_MAIN, spp=a.spp, size=n,
@@ -76,7 +90,7 @@ def main(argv=None):
 
     def render(v, part=0, n_parts=0):
         c = cams[v]
-        ds.render_to_device(device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])), frame.data_ptr(), view=v,
+        ds.render_to_device(device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])), frame.data_ptr(), view=first_view + v,
                             part=part, n_parts=n_parts, **opt)
         return frame if a.backend == "nccl" else frame.cpu()
 
@@ -84,7 +98,7 @@ def main(argv=None):
         """Views first, first + stride, ... in one library call, which keeps several of them in flight on the GPU."""
         sel = cams[first: first + stride * count: stride]
         frames, _ = ds.render_views([device.make_camera(c[:3].tolist(), float(c[3]), float(c[4])) for c in sel],
-                                    view0=first, view_stride=stride, **opt)
+                                    view0=first_view + first, view_stride=stride, **opt)
         return frames.reshape(count, -1)
 
     t_last = [time.perf_counter()]
@@ -100,7 +114,7 @@ def main(argv=None):
             if item is None:
                 return
             try:
-                host.write_image(os.path.join(a.out, f"{a.scene}{item[0]}.ppm"), item[1].reshape(n, n, 3))
+                host.write_image(os.path.join(a.out, f"{a.scene}{first_view + item[0]}.ppm"), item[1].reshape(n, n, 3))
             except Exception as e:                                                                      # reported after the loop
                 failed.append(e)
 

@@ -197,6 +197,46 @@ def test_bench_with_two_ranks_started_by_itself(cbox):
     assert abs(many[0]["views_per_s"] * many[0]["ms_per_step"] * 1e-3 - 6.0) < 0.01
 
 
+def test_resume_keeps_whole_frames_and_renders_the_rest(tmp_path):
+    """--resume: the -rm job goes on where an earlier one stopped.  Frame files that are there and whole are kept (not even
+    opened for writing), missing and truncated ones are rendered; the files end up those of an uninterrupted job."""
+    import sys
+    full, part = tmp_path / "full", tmp_path / "part"
+    args = ["cbox", "-rm", "-gi", "--views", "6", "--size", "48", "--spp", "2"]
+    for mode in ("loop", "all"):                                 # the plain loop of ptmain, and pt_render_views in batches
+        extra = ["--gpus", "all"] if mode == "all" else []
+        for d in (full, part):
+            if d.exists():
+                for f in d.iterdir():
+                    f.unlink()
+            else:
+                os.makedirs(d)
+        run(args + extra, full)
+        run(args + extra, part)
+        (part / "cbox3.ppm").unlink()
+        whole = (part / "cbox4.ppm").read_bytes()
+        (part / "cbox4.ppm").write_bytes(whole[: len(whole) // 2])
+        stamp = {k: (part / f"cbox{k}.ppm").stat().st_mtime_ns for k in (0, 1, 2)}
+        out = run(args + extra + ["--resume"], part)
+        for k in range(6):
+            assert (part / f"cbox{k}.ppm").read_bytes() == (full / f"cbox{k}.ppm").read_bytes(), (mode, k)
+        for k in (0, 1, 2):
+            assert (part / f"cbox{k}.ppm").stat().st_mtime_ns == stamp[k], (mode, k)
+        assert ("Resuming at view 3 of 6" in out) if mode == "all" else (out.count("kept ") == 4)
+    # the one-process-per-GPU job
+    rm = [sys.executable, "-m", "pathtracing_amd.rm", "cbox", "-gi", "--views", "6", "--size", "48", "--spp", "2"]
+    a, b = tmp_path / "rm_full", tmp_path / "rm_part"
+    for d in (a, b):
+        r = subprocess.run(rm + ["--out", str(d)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+    for k in (2, 3, 4, 5):
+        (b / f"cbox{k}.ppm").unlink()
+    r = subprocess.run(rm + ["--out", str(b), "--resume"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Resuming at view 2 of 6" in r.stdout, r.stdout + r.stderr
+    for k in range(6):
+        assert (b / f"cbox{k}.ppm").read_bytes() == (a / f"cbox{k}.ppm").read_bytes(), k
+
+
 def test_a_view_that_fails_gets_a_second_attempt_on_another_worker(cbox, monkeypatch):
     """A view whose render fails on one worker of pt_render_views is rendered again by a worker that is in order; the frames
     and ray counts are those of the undisturbed job.  With a single worker there is nobody to take it: the call fails and
