@@ -11,6 +11,10 @@
 #pragma once
 #include "pt_trace_f32.h"
 
+#ifndef PT_QUAD_MERGED
+#define PT_QUAD_MERGED 0
+#endif
+
 struct LaneStateQ {
     float ox, oy, oz, ix, iy, iz;
     f32x2 dtx, dty, dtz;
@@ -74,6 +78,45 @@ __device__ __forceinline__ bool lane_turn(LaneStateQ &L, const DevScene &S, uint
     }
     if (active & !(at_leaf & (L.n0 < L.n1)) & !done) {
         uint32_t curr;
+#if PT_QUAD_MERGED
+        // One straight-line block for both kinds of step (a wave nearly always holds lanes of both kinds, and an if / else
+        // is walked twice by such a wave): the quad step's numbers are formed by every lane and used by the lanes on a quad
+        // record (q), the pop by the lanes on a finished leaf.
+        {
+            const bool q = !at_leaf;
+            const uint32_t link = L.nlink, base = link & ~63u;
+            const float s0 = __uint_as_float(L.n0), s1 = __uint_as_float(L.n1), s2 = __uint_as_float(L.n2);
+            uint32_t h1; bool both0; float t0;
+            plane_q(L, link & 3u, s0, L.ent, L.ext, h1, both0, t0);
+            const float e1 = both0 ? t0 : L.ext;
+            const bool second = q & both0 & (t0 < L.tmin);
+            uint32_t ga, gb; bool botha, bothb; float ta, tb;
+            plane_q(L, (link >> (h1 ? 4 : 2)) & 3u, h1 ? s2 : s1, L.ent, e1, ga, botha, ta);
+            plane_q(L, (link >> (h1 ? 2 : 4)) & 3u, h1 ? s1 : s2, t0, L.ext, gb, bothb, tb);
+            const uint32_t slot_a = base + (h1 * 2u + ga) * 16u, slot_b = base + ((h1 ^ 1u) * 2u + gb) * 16u;
+            push_q(L, S, stk, slot_mask, second & bothb & (tb < L.tmin), slot_b ^ 16u, L.ext);
+            push_q(L, S, stk, slot_mask, second, slot_b, bothb ? tb : L.ext);
+            push_q(L, S, stk, slot_mask, q & botha & (ta < L.tmin), slot_a ^ 16u, e1);
+            // leaf done: the next segment starts where this one ended
+            const uint32_t cnt = L.cs & 0xFFu;
+            const bool finished = at_leaf & (L.ext >= L.tmin);
+            const bool cont = at_leaf & !finished;
+            const bool pop_ring = cont & (cnt != 0);
+            const bool pop_ovf = cont & (cnt == 0) & (L.novf != 0);
+            const bool exhausted = cont & (cnt == 0) & (L.novf == 0);
+            const uint32_t ptop = (L.top - 1u) & slot_mask;
+            uint2 e = stk[ptop * 64];
+            if (pop_ovf) { L.novf--; e = overflow_column(S)[(size_t)L.novf * 64]; }
+            const bool pop = pop_ring | pop_ovf;
+            curr = q ? slot_a : (pop ? e.x : 0u);
+            const float ext_q = botha ? ta : e1, ext_l = pop ? __uint_as_float(e.y) : L.ext;
+            L.ent = q ? L.ent : L.ext;
+            L.ext = q ? ext_q : ext_l;
+            L.top = pop_ring ? ptop : L.top;
+            L.cs += 256u - (uint32_t)pop_ring;
+            done = finished | exhausted;
+        }
+#else
         if (!at_leaf) {
             // ---- two levels down: up to four grandchildren in front-to-back order; the first is taken, the others pushed ----
             const uint32_t link = L.nlink, base = link & ~63u;
@@ -110,6 +153,7 @@ __device__ __forceinline__ bool lane_turn(LaneStateQ &L, const DevScene &S, uint
             L.cs += 256u - (uint32_t)pop_ring;
             done = finished | exhausted;
         }
+#endif
         const bool runaway = L.cs > ((uint32_t)FS_MAX_STEPS << 8);
         if (runaway) atomicOr((unsigned int *)S.err, (unsigned int)PT_LIMIT_F32_STEPS);
         done = done | runaway;

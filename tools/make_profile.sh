@@ -29,6 +29,6 @@ j = json.load(open('$OUT/bench_under_trace.json'))
 print('# kernel_source_hash', bench.kernel_source_hash())
 print('# rays_per_launch', j['roofline']['rays_per_launch'])")
 { echo "$HDR"; python3 tools/pmc_summary.py "$OUT" "k_trace_closest<false"; } > "$OUT/pmc_k_trace_closest.txt"
-{ echo "$HDR"; python3 tools/pmc_summary.py "$OUT" "k_primary_exact"; } > "$OUT/pmc_k_primary_exact.txt"
+{ echo "$HDR"; for k in "k_primary_search" "k_primary_shade" "k_primary_again" "k_packet_prep" "k_mirror_exact"; do python3 tools/pmc_summary.py "$OUT" "$k"; done; } > "$OUT/pmc_k_primary.txt"
 { echo "$HDR"; python3 tools/pmc_summary.py "$OUT" "k_shade_sum_omp"; python3 tools/pmc_summary.py "$OUT" "k_gi_gen"; } > "$OUT/pmc_k_shade_gen.txt"
 ls "$OUT/trace"

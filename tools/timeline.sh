@@ -19,7 +19,7 @@ j = json.load(open(os.path.join(out, "bench.json")))
 tr = [r for r in rows if "k_trace_closest<false" in r[2]]
 per_step = len(tr) // (j["steps"] + j["warmup"])
 first = tr[j["warmup"] * per_step]
-prim = [r for r in rows if "k_primary_exact" in r[2] and r[0] <= first[0]]
+prim = [r for r in rows if ("k_packet_prep" in r[2] or "k_primary_search" in r[2]) and r[0] <= first[0]]
 t0 = prim[-1][0]
 t1 = tr[(j["steps"] + j["warmup"]) * per_step - 1][1]
 # the view ends with k_resolve after the last trace
@@ -47,7 +47,7 @@ for n, b in sorted(busy.items(), key=lambda x: -x[1]):
 tt = sum(b for n, b in busy.items() if "k_trace_closest<false" in n)
 print(f"not covered by the closest-hit kernel: {span - tt:.2f} ms = {100 * (1 - tt / span):.1f} %")
 # the kernels of the last timed step in start order (ms from the step's first kernel)
-steps_prim = [r for r in rows if "k_primary_exact" in r[2] and t0 <= r[0] <= t1]
+steps_prim = [r for r in rows if "k_packet_prep" in r[2] and t0 <= r[0] <= t1]
 if steps_prim:
     b = steps_prim[-1][0]
     print("last step, kernel by kernel (start .. end, ms):")
