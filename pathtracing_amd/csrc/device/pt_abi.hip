@@ -93,6 +93,7 @@ struct PtScene {
     hipStream_t stream_gen = nullptr;         // ray generation of the next GI pass runs here, beside the current pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;   // around the primary pass of a view
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;     // fork and join of the part of the primary pass that runs on stream_gen
     std::vector<hipEvent_t> pass_events;      // a pair per GI pass of a view (fp32 path), grown on demand
     int max_depth = 0;
     RefineStats refine;
@@ -531,6 +532,8 @@ int finish_scene(uint8_t *slab, const SlabHeader &H, int device, PtScene **out, 
     if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev_p0);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev_p1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_a, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_b, hipEventDisableTiming);
     if (e != hipSuccess) return fail(PT_ERR_HIP, std::string("stream/event creation: ") + hipGetErrorString(e));
     *out = holder.release();
     return PT_OK;
@@ -695,7 +698,7 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     DevScene S = sc->S;
     S.err = F.counters + RC_LIMITS;
     if (st) HIPCHK(hipEventRecord(sc->ev_p0, s));
-    if (exact_primary(S, V, F, sc->ws.B, s)) return fail(PT_ERR_HIP, "primary pass launch failed");
+    if (exact_primary(S, V, F, sc->ws.B, s, sc->stream_gen, sc->ev_a, sc->ev_b)) return fail(PT_ERR_HIP, "primary pass launch failed");
     if (st) HIPCHK(hipEventRecord(sc->ev_p1, s));
     *gi_ms = 0; *gi_launches = 0;
     uint64_t fast_rays = 0, fast_shadow = 0, fast_work[2] = {0, 0};
@@ -957,6 +960,8 @@ int pt_scene_free(PtScene *sc) {
     if (sc->ev1) (void)hipEventDestroy(sc->ev1);
     if (sc->ev_p0) (void)hipEventDestroy(sc->ev_p0);
     if (sc->ev_p1) (void)hipEventDestroy(sc->ev_p1);
+    if (sc->ev_a) (void)hipEventDestroy(sc->ev_a);
+    if (sc->ev_b) (void)hipEventDestroy(sc->ev_b);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
     if (sc->stream_gen) (void)hipStreamDestroy(sc->stream_gen);
     if (sc->stream) (void)hipStreamDestroy(sc->stream);

@@ -460,7 +460,7 @@ static unsigned resident_waves(K kernel, size_t work_blocks, size_t lds_bytes = 
     return (unsigned)(w < 1 ? 1 : w);
 }
 
-int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const SubBuffers &B, hipStream_t s) {
+int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const SubBuffers &B, hipStream_t s, hipStream_t s2, hipEvent_t ev_a, hipEvent_t ev_b) {
     const size_t P = (size_t)V.size * V.size;
     const unsigned cblocks = (unsigned)((P + 255) / 256);
     const unsigned blocks = V.rb ? (unsigned)(((size_t)tile_threads(V.size) * 9 + 62) / 63) : (unsigned)(tile_threads(V.size) / 64);
@@ -480,9 +480,13 @@ int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F,
         const size_t slots = P * (V.rb ? 9 : 1);
         hipLaunchKernelGGL(k_primary_search<PT_MODEL_OMP>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_PKT_LDS_BYTES, s, PA);
         const size_t sblocks = (slots + 255) / 256;
+        // The listed sub-rays (few; the list's length is on the device) run on the second stream beside the shading of the others:
+        // a handful of waves that each make a whole search alone are latency, not load, and the two kernels write different sub-rays.
+        const bool side = s2 && ev_a && ev_b && hipEventRecord(ev_a, s) == hipSuccess && hipStreamWaitEvent(s2, ev_a, 0) == hipSuccess;
+        hipLaunchKernelGGL(k_primary_again, dim3(128), dim3(64), PT_RING64_LDS_BYTES, side ? s2 : s, S, V, F, B);
+        if (side && hipEventRecord(ev_b, s2) != hipSuccess) return PT_ERR_HIP;
         hipLaunchKernelGGL(k_primary_shade_omp, dim3((unsigned)(sblocks < 2048 ? sblocks : 2048)), dim3(256), 0, s, S, V, F, B);
-        // the listed sub-rays: few, so a grid of one wave per SIMD-quarter of the chip is plenty (the list's length is on the device)
-        hipLaunchKernelGGL(k_primary_again, dim3(256), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B);
+        if (side && hipStreamWaitEvent(s, ev_b, 0) != hipSuccess) return PT_ERR_HIP;
         if (S.any_mirror) hipLaunchKernelGGL(k_mirror_exact<PT_MODEL_OMP>, dim3(blocks < wm ? blocks : wm), dim3(64), PT_RING64_LDS_BYTES, s, S, V, F, B, blocks);
         hipLaunchKernelGGL(k_primary_combine<PT_MODEL_OMP>, dim3(cblocks), dim3(256), 0, s, F, B, V.size, V.rb, V.part, V.n_parts);
     }

@@ -77,7 +77,9 @@ static inline int tile_threads(int size) { int t = (size + 7) >> 3; return t * t
 
 // ---- pt_exact.hip ----
 #define PT_EXACT_WAVES 4096u       // one-wave blocks of a launch of an fp64 search kernel (each owns a stack overflow region)
-int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const SubBuffers &B, hipStream_t s);
+// s2, ev_a, ev_b (optional): a second stream and two events for the part of the pass that can run beside the rest
+int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const SubBuffers &B, hipStream_t s, hipStream_t s2 = nullptr,
+                  hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
 int exact_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, int s0, int nb, hipStream_t s);
 int gi_accumulate(const FrameBuffers &F, int size, int nb, int first_batch, hipStream_t s);
 int resolve_frame(const FrameBuffers &F, int size, int gi, int nsamples, hipStream_t s);

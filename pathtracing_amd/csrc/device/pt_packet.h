@@ -225,7 +225,9 @@ PT_DEV PacketRay packet_ray(const RayD &r) {
 
 // KDNode::searchNode (util/kdtree.cpp:180-197) for the rays `in` of the packet on the list of node `node0`.
 // forms: the view's table of k_packet_prep, four arrays of n_ref entries (det, un, vn, w).
-PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, const RayD &ray, bool in, const PacketBoundsF &B,
+// second: this ray is in its second search (see packet_search): a triangle that would improve on the bound is reported, the
+// hit record stays as the first search left it.
+PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, const RayD &ray, bool in, bool second, const PacketBoundsF &B,
                         const float4 *forms, HitD &h) {
     const uint32_t lane = threadIdx.x & 63u;
     bool improved = false;
@@ -262,8 +264,7 @@ PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, co
                     const D3 lo = uload3(b), hi = uload3(b + 3);
                     if (hit.x >= lo.x && hit.y >= lo.y && hit.z >= lo.z && hit.x <= hi.x && hit.y <= hi.y && hit.z <= hi.z) {
                         improved = true;
-                        h.tmin = t; h.u = bu; h.v = bv;
-                        h.tri = cur.id;
+                        if (!second) { h.tmin = t; h.u = bu; h.v = bv; h.tri = cur.id; }
                     }
                 }
             }
@@ -280,7 +281,19 @@ PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, co
 }
 
 // The search of every `live` ray of the wave: src (the same for all) and `dir`; h.tmin is the in/out bound as in
-// search_ref_t, whose result and notes this returns.  Every lane of the wave must call it.
+// search_ref_t, whose result this returns.  Every lane of the wave must call it.
+//
+// NOTED (mainOMP model): the walk also answers the question of SearchNote -- can the second search of mainOMP.cpp:60, the
+// same ray bounded by the hit just found, find anything? -- and answers it by doing what is left of that search.  The second
+// search repeats the first one's decisions and finds nothing on the way, unless a far-only step lay beyond the hit (far_max,
+// as in search_ref_t); having arrived where the first search returned, it goes on with the entries the first search left on
+// the stack.  The walk is standing right there with those entries in hand: a ray that has its hit (state `second`) takes up
+// an entry that starts before the hit under the second search's own rules (the bound is the hit's distance), ends at one
+// that starts AT the hit (util/kdtree.cpp:229-231), and passes over one that starts beyond it (the second search never
+// pushed it, :246).  Only a triangle that would improve on the bound makes the note say "run it" (stack_min = -DBL_MAX);
+// otherwise stack_min stays +DBL_MAX.  tests/packet_check.c states this in C and checks, ray by ray, that the second search
+// as written is the first one's walk thinned out followed by exactly this resumed walk: on the atrium 1 095 of 6.2 M camera
+// rays left such entries, each resumed walk was 2 or 3 nodes long, none found anything.
 template <bool NOTED>
 PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, const PacketBoundsF &B, const float4 *forms, HitD &h, SearchNote *note, double *lds) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -290,7 +303,8 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, cons
     double ent = 0, ext = 0;
     if (NOTED) { note->far_max = -DBL_MAX; note->stack_min = DBL_MAX; }
     bool in = live && box_intersect(S.root_lo, S.root_hi, ray, ent, ext) && !(ent >= h.tmin);
-    bool finished = !in;                            // this ray's search has ended (or never began)
+    bool finished = !in;                            // this ray's first search has ended (or never began)
+    bool second = false;                            // ... with a hit at a leaf, and its second search has not ended
     bool found = false, at_leaf = false;
     unsigned long long act = __ballot(in);
     int curr = 0;
@@ -298,16 +312,20 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, cons
     // the (new) current node, does that node.
     for (;;) {
         if (!act) {
-            if (st.sp == 0 || (!NOTED && !__ballot(!finished))) break;
+            if (st.sp == 0 || !__ballot(!finished || second)) break;
             unsigned long long pushm, deferm;
             st.pop(curr, pushm, deferm);
             in = (deferm >> lane) & 1ull;
             if ((pushm >> lane) & 1ull) {
                 double e, x;
                 st.popped(e, x);
-                if (finished) { if (NOTED && e < note->stack_min) note->stack_min = e; }
-                else if (e >= h.tmin) finished = true;          // util/kdtree.cpp:229-231: ends this ray's search
-                else { ent = e; ext = x; in = true; }
+                if (!finished) {
+                    if (e >= h.tmin) finished = true;               // util/kdtree.cpp:229-231: ends this ray's search (and a second one at the same entry)
+                    else { ent = e; ext = x; in = true; }
+                } else if (NOTED && second) {
+                    if (e < h.tmin) { ent = e; ext = x; in = true; }
+                    else if (e == h.tmin) second = false;
+                }
             }
             act = __ballot(in);
         }
@@ -315,9 +333,13 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, cons
             const NodeA nd = load_node_u(S, curr);
             const int axis = nd.axis, left = nd.left;
             bool improved = false;
-            if (nd.count > 0) improved = packet_node(S, curr, nd.first, nd.count, ray, in, B, forms, h);
+            if (nd.count > 0) improved = packet_node(S, curr, nd.first, nd.count, ray, in, NOTED && second, B, forms, h);
+            if (NOTED && in && second && improved) {    // the second search would find something: it has to be run as written
+                note->stack_min = -DBL_MAX;
+                second = false; in = false; improved = false;
+            }
             if (axis < 0) {                          // a leaf: the rays that improved their hit here are done (:252-253)
-                if (in && improved) { at_leaf = true; finished = true; }
+                if (in && improved) { at_leaf = true; finished = true; second = NOTED; }
                 act = 0;
             } else {
                 found |= in && improved;
@@ -328,23 +350,24 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, cons
                 const bool far_only = !near_only && tmid <= ent && tmid <= h.tmin;
                 const bool push = !near_only && !far_only && tmid <= h.tmin;
                 const unsigned long long nearm = __ballot(in && !far_only), farm = __ballot(in && far_only), pushm = __ballot(in && push);
-                if (NOTED && in && far_only && tmid > note->far_max) note->far_max = tmid;
+                if (NOTED && in && !second && far_only && tmid > note->far_max) note->far_max = tmid;
                 const bool swap = sa > nd.split;     // the same for every ray: they share src
                 const int nr = swap ? left + 1 : left, fr = swap ? left : left + 1;
+                bool overflow = false;
                 if (nearm) {
                     if (farm | pushm) {
-                        if (st.sp >= 64u || (st.sp >= PT_PKT_LDS && (st.sp - PT_PKT_LDS) * 2u + 2u > S.ovf64_entries * 3u)) {
-                            atomicOr(S.err, (unsigned long long)PT_LIMIT_F64_STACK);  // cannot happen for a tree of the uploaded depth
-                            st.sp = 0; act = 0; finished = true;                      // ends the walk
-                        } else {
-                            st.push(fr, pushm, farm, in && push, tmid, ext);
-                        }
+                        overflow = st.sp >= 64u || (st.sp >= PT_PKT_LDS && (st.sp - PT_PKT_LDS) * 2u + 2u > S.ovf64_entries * 3u);
+                        if (!overflow) st.push(fr, pushm, farm, in && push, tmid, ext);
                     }
                     if (in && !near_only && !far_only) ext = tmid;
                     in = in && !far_only;
-                    curr = nr; act = act ? nearm : 0;
+                    curr = nr; act = nearm;
                 } else {
-                    curr = fr; act = farm;
+                    curr = fr; act = farm;           // (both masks empty: the rays that were here have all just left the walk)
+                }
+                if (overflow) {                      // cannot happen for a tree of the uploaded depth; ends the walk, the call fails
+                    atomicOr(S.err, (unsigned long long)PT_LIMIT_F64_STACK);
+                    st.sp = 0; act = 0; finished = true; second = false;
                 }
             }
         }

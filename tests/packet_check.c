@@ -8,7 +8,9 @@
  * its own numbers, and meets its nodes and triangles in the order of its own search.  Before the rays of the packet
  * test the triangles of a node, the packet as a whole is tested against them (one triangle per lane): a triangle that
  * provably none of the packet's rays can hit is left out.  This file states both parts in plain C:
- *     packet_search()   the walk, with the notes the device keeps for mainOMP.cpp:60 (see research_check.c)
+ *     packet_search()   the walk; for mainOMP.cpp:60 (see research_check.c) it notes far-only steps beyond the hit and goes
+ *                       on, for a ray that has its hit, with the part of the second search that lies behind the point where
+ *                       the first one returned -- the walk is standing there with the ray's stack entries in hand
  *     packet_cull()     the conservative packet-vs-triangle test as the proof is written: fp64, margin 1e-12
  *     packet_cull_f()   the test the device runs: the same linear forms per (camera, triangle), divided by their
  *                       magnitude bounds and rounded to fp32, ranges evaluated in fp32, margin 1e-5; every triangle
@@ -25,7 +27,7 @@ typedef unsigned long long u64;
 
 typedef struct {
     long packets, rays, node_visits, lists, list_entries, survivors, lane_tests, any_pass, pushes, pops, max_depth;
-    long ref_node_visits, ref_tri_tests, loose, kept64;
+    long ref_node_visits, ref_tri_tests, loose, kept64, n_again, n_again_old, n_found2, n_resumed_nodes;
     long depth_hist[64];
 } PStats;
 
@@ -84,6 +86,97 @@ static int packet_cull(const Bundle *B, V3 o, V3 v0, V3 e1, V3 e2) {
     return ulo > mu || vlo > mv || whi < -mw || tn > mt;
 }
 
+/* ---- the second search, ray by ray, for the structural check below ------------------------------------------------ */
+#define TRACE_MAX 4096
+typedef struct { const KD *n[TRACE_MAX]; int cnt; } Trace;
+static inline void trace_add(Trace *t, const KD *n) { if (t->cnt < TRACE_MAX) t->n[t->cnt] = n; t->cnt++; }
+
+/* search() of util/kdtree.cpp:216-257 with the nodes it visits written down; on return the entries left on its stack
+   (bottom first) are in sn / se / sx, *left of them.  With resume != 0 the search does not start at the root but goes on
+   from such a stack under the rules of the second search described at packet_search(): the bound h->tmin stays, an entry
+   that starts at the bound ends the search, one that starts beyond it is passed over; a triangle that would improve on
+   the bound ends it with 2. */
+static int search_traced(const Scene *s, const Ray *ray, Hit *h, Trace *tr, const KD **sn, double *se, double *sx, int *left, int resume) {
+    double ent, ext;
+    const KD *curr = s->root;
+    Cnt c; memset(&c, 0, sizeof c);
+    int sp = resume ? *left : 0, found = 0, ret = -1;
+    const double bound = h->tmin;
+    if (!resume) {
+        if (!box_intersect(curr->lo, curr->hi, ray, &ent, &ext)) { *left = 0; return 0; }
+        sn[sp] = curr; se[sp] = ent; sx[sp] = ext; sp++;
+    }
+    while (sp > 0 && ret < 0) {
+        sp--;
+        curr = sn[sp]; ent = se[sp]; ext = sx[sp];
+        if (resume) {
+            if (ent > bound) continue;
+            if (ent == bound) break;
+        } else if (ent >= h->tmin) break;
+        while (!curr->leaf) {
+            trace_add(tr, curr);
+            Hit before = *h;
+            int f = search_node(s, curr, ray, h, &c);
+            if (resume && f) { *h = before; *left = sp; return 2; }
+            found |= f;
+            double sp_ = curr->splt;
+            int a = curr->axis;
+            double da = vget(ray->dir, a);
+            double tdir = da == 0 ? 0.0000001 : da;
+            double tmid = (sp_ - vget(ray->src, a)) / tdir;
+            const KD *nr = curr->left, *fr = curr->right;
+            if (vget(ray->src, a) > sp_) { const KD *x = nr; nr = fr; fr = x; }
+            if (tmid >= ext || tmid < 0)
+                curr = nr;
+            else if (tmid <= ent && tmid <= h->tmin)
+                curr = fr;
+            else {
+                if (tmid <= h->tmin) { sn[sp] = fr; se[sp] = tmid; sx[sp] = ext; sp++; }
+                curr = nr;
+                ext = tmid;
+            }
+        }
+        trace_add(tr, curr);
+        Hit before = *h;
+        if (search_node(s, curr, ray, h, &c)) {
+            if (resume) { *h = before; *left = sp; return 2; }
+            ret = 1;
+        }
+    }
+    *left = sp;
+    return ret > 0 ? 1 : found;
+}
+
+/* For a ray whose first search returned a hit AT A LEAF: is the second search as written (from the root, bounded by the
+   hit) the first search's walk, thinned out, followed by exactly the walk that resumes from the first search's stack?
+   0: yes.  Also hands out the resumed walk for comparison with what the packet walk did for this ray. */
+static int second_search_structure(const Scene *s, const Ray *ray, Trace *resumed, int *resumed_ret) {
+    static _Thread_local Trace t1, t2;
+    const KD *sn[STK]; double se[STK], sx[STK];
+    const KD *qn[STK]; double qe[STK], qx[STK];
+    int left = 0, qleft = 0;
+    Hit h1; h1.tmin = FLT_MAX; h1.m = h1.t = -1; h1.u = h1.v = 0;
+    t1.cnt = t2.cnt = resumed->cnt = 0;
+    if (!search_traced(s, ray, &h1, &t1, sn, se, sx, &left, 0)) return -1;
+    Hit h2 = h1; h2.m = h2.t = -1; h2.u = h2.v = 0;
+    const int f2 = search_traced(s, ray, &h2, &t2, qn, qe, qx, &qleft, 0);
+    Hit h3 = h1;
+    *resumed_ret = search_traced(s, ray, &h3, resumed, sn, se, sx, &left, 1);
+    if (t1.cnt > TRACE_MAX || t2.cnt > TRACE_MAX || resumed->cnt > TRACE_MAX) return -2;
+    if (f2) return *resumed_ret == 2 ? 0 : 1;              /* it finds something: the resumed walk must have met it (suspect) */
+    if (*resumed_ret == 2) return 2;
+    if (resumed->cnt > t2.cnt) return 3;
+    const int head = t2.cnt - resumed->cnt;
+    for (int i = 0; i < resumed->cnt; i++) if (t2.n[head + i] != resumed->n[i]) return 4;
+    int j = 0;                                              /* the head: a subsequence of the first search's walk */
+    for (int i = 0; i < head; i++) {
+        while (j < t1.cnt && t1.n[j] != t2.n[i]) j++;
+        if (j == t1.cnt) return 5;
+        j++;
+    }
+    return 0;
+}
+
 /* The device's form of the test (pt_packet.h: packet_forms, packet_bounds_f, packet_cull). */
 typedef struct { float f[4][3]; float tsign; } Forms;
 static Forms packet_forms(const Bundle *B, V3 o, V3 v0, V3 e1, V3 e2) {
@@ -131,7 +224,9 @@ static int packet_cull_f(const Bundle *B, const Forms *F) {
 typedef struct { const KD *node; u64 push, defer; double ent[PW], ext[PW]; } PEntry;
 
 /* One node's list for the rays in `act`; returns the mask of rays that improved their hit here. */
-static u64 packet_node(const Scene *s, const KD *nd, const Ray *rays, u64 act, const Bundle *B, Hit *h, PStats *ps, int cull) {
+/* m2: the rays that are in their SECOND search (mainOMP.cpp:60, bounded by the hit of the first): a triangle that would
+   improve on the bound is only reported (bit in the result), the hit record stays as the first search left it. */
+static u64 packet_node(const Scene *s, const KD *nd, const Ray *rays, u64 act, u64 m2, const Bundle *B, Hit *h, PStats *ps, int cull) {
     u64 improved = 0;
     ps->lists++;
     for (int i = 0; i < nd->n; i++) {
@@ -161,6 +256,7 @@ static u64 packet_node(const Scene *s, const KD *nd, const Ray *rays, u64 act, c
                           hit.x <= nd->hi.x && hit.y <= nd->hi.y && hit.z <= nd->hi.z))
                         continue;
                     improved |= 1ull << l;
+                    if (m2 >> l & 1) continue;
                     h[l].tmin = t; h[l].u = bu; h[l].v = bv; h[l].m = nd->m[i]; h[l].t = nd->t[i];
                 }
             }
@@ -171,19 +267,29 @@ static u64 packet_node(const Scene *s, const KD *nd, const Ray *rays, u64 act, c
 }
 
 /* The packet walk.  rays[l] for l in live share their origin.  ret[l] = what search() returns for ray l. */
-static void packet_search(const Scene *s, const Ray *rays, u64 live, double sa, double ca, Hit *h, int *ret, Note *note, PStats *ps, int cull) {
+/* States of a ray of the packet.  FIRST: in its first search.  OVER: that search ended without a hit (or never began).
+   SECOND: the first search returned a hit at a leaf; the ray now stands where the second search of mainOMP.cpp:60 -- the
+   same ray bounded by that hit -- stands after repeating the first one's decisions (research_check.c: it repeats them and
+   finds nothing, unless a far-only step lay beyond the hit, which far_max reports), and goes on from there on the entries
+   the first search left on the stack: an entry that starts before the hit is visited under the second search's own rules,
+   one that starts AT the hit ends it (util/kdtree.cpp:229-231), one that starts beyond it was never pushed by the second
+   search (:246) and is passed over.  ENDED: the second search has ended, or has met a triangle that improves on the
+   bound (`suspect`: then the device runs the second search as written). */
+enum { FIRST = 0, OVER = 1, SECOND = 2, ENDED = 3 };
+
+static void packet_search(const Scene *s, const Ray *rays, u64 live, double sa, double ca, Hit *h, int *ret, Note *note, int *suspect_out, Trace *second, PStats *ps, int cull) {
     static _Thread_local PEntry stack[STK];
     double ent[PW], ext[PW];
-    u64 act = 0, done = ~live, found = 0;
+    int state[PW];
+    u64 act = 0, found = 0, suspect = 0;
     int sp = 0;
     const KD *curr = s->root;
     Bundle B = bundle_of(rays, live, sa, ca);
     for (int l = 0; l < PW; l++) {
-        ret[l] = 0;
+        ret[l] = 0; state[l] = OVER;
         note[l].far_max = -INFINITY; note[l].stack_min = INFINITY;
         if (!(live >> l & 1)) continue;
-        if (box_intersect(curr->lo, curr->hi, &rays[l], &ent[l], &ext[l]) && !(ent[l] >= h[l].tmin)) act |= 1ull << l;
-        else done |= 1ull << l;
+        if (box_intersect(curr->lo, curr->hi, &rays[l], &ent[l], &ext[l]) && !(ent[l] >= h[l].tmin)) { act |= 1ull << l; state[l] = FIRST; }
     }
     ps->packets++;
     for (;;) {
@@ -193,9 +299,15 @@ static void packet_search(const Scene *s, const Ray *rays, u64 live, double sa, 
                 ps->pops++;
                 for (int l = 0; l < PW; l++) {
                     if (e->push >> l & 1) {
-                        if (done >> l & 1) { if (e->ent[l] < note[l].stack_min) note[l].stack_min = e->ent[l]; }
-                        else if (e->ent[l] >= h[l].tmin) done |= 1ull << l;        /* util/kdtree.cpp:229-231 */
-                        else { ent[l] = e->ent[l]; ext[l] = e->ext[l]; act |= 1ull << l; }
+                        if (state[l] == FIRST) {
+                            if (e->ent[l] >= h[l].tmin) {                               /* util/kdtree.cpp:229-231: the first search ends */
+                                /* with a hit from an interior node the second search ends at this very entry too */
+                                state[l] = (found >> l & 1) ? ENDED : OVER;
+                            } else { ent[l] = e->ent[l]; ext[l] = e->ext[l]; act |= 1ull << l; }
+                        } else if (state[l] == SECOND) {
+                            if (e->ent[l] < h[l].tmin) { ent[l] = e->ent[l]; ext[l] = e->ext[l]; act |= 1ull << l; }
+                            else if (e->ent[l] == h[l].tmin) state[l] = ENDED;
+                        }
                     } else if (e->defer >> l & 1) act |= 1ull << l;
                 }
                 curr = e->node;
@@ -203,14 +315,18 @@ static void packet_search(const Scene *s, const Ray *rays, u64 live, double sa, 
             if (!act) break;
         }
         ps->node_visits++;
-        u64 improved = curr->n > 0 ? packet_node(s, curr, rays, act, &B, h, ps, cull) : 0;
+        u64 m2 = 0;
+        for (int l = 0; l < PW; l++) if ((act >> l & 1) && state[l] == SECOND) { m2 |= 1ull << l; trace_add(&second[l], curr); }
+        u64 improved = curr->n > 0 ? packet_node(s, curr, rays, act, m2, &B, h, ps, cull) : 0;
+        for (int l = 0; l < PW; l++) if (improved & m2 & (1ull << l)) { suspect |= 1ull << l; state[l] = ENDED; }
+        act &= ~(improved & m2);
         if (curr->leaf) {
-            for (int l = 0; l < PW; l++) if (improved >> l & 1) ret[l] = 1;
-            done |= improved;
+            for (int l = 0; l < PW; l++) if ((improved & ~m2) >> l & 1) { ret[l] = 1; state[l] = SECOND; }
             act = 0;
             continue;
         }
-        found |= improved;
+        found |= improved & ~m2;
+        if (!act) continue;
         u64 nearm = 0, faronly = 0, pushm = 0;
         double tmidv[PW];
         const int a = curr->axis;
@@ -224,7 +340,7 @@ static void packet_search(const Scene *s, const Ray *rays, u64 live, double sa, 
             if (tmid >= ext[l] || tmid < 0) nearm |= 1ull << l;
             else if (tmid <= ent[l] && tmid <= h[l].tmin) {
                 faronly |= 1ull << l;
-                if (tmid > note[l].far_max) note[l].far_max = tmid;
+                if (state[l] == FIRST && tmid > note[l].far_max) note[l].far_max = tmid;
             } else {
                 nearm |= 1ull << l;
                 if (tmid <= h[l].tmin) pushm |= 1ull << l;
@@ -250,11 +366,13 @@ static void packet_search(const Scene *s, const Ray *rays, u64 live, double sa, 
         ps->depth_hist[sp < 63 ? sp : 63]++;
     }
     for (int l = 0; l < PW; l++) if ((live >> l & 1) && !ret[l]) ret[l] = (int)(found >> l & 1);
+    for (int l = 0; l < PW; l++) suspect_out[l] = (int)(suspect >> l & 1);
 }
 
 /* Camera rays of one view in the device's packets: with rb, strips of 7 pixels of a row x 9 sub-rays (63 lanes);
    without, 8x8 pixel tiles.  Rows row0, row0 + row_step, ... (tiles: tile rows).  out: [0] rays, [1] rays whose result
-   differs from search_ref (must be 0), [2] rays whose notes differ from search_noted (must be 0), then the PStats. */
+   differs from search_ref (must be 0), [2] rays whose far_max differs from search_noted's, or whose second search as written
+   finds something although the walk says it need not be run (must be 0), then the PStats. */
 void packet_check(const Scene *s, const double eye[3], double angle, double zoom, int size, int rb, double off,
                   int row0, int row_step, int cull, long *out, PStats *stats) {
     V3 src = v3(eye[0], eye[1], eye[2]);
@@ -286,9 +404,11 @@ void packet_check(const Scene *s, const double eye[3], double angle, double zoom
                 live |= 1ull << l;
             }
             if (!live) continue;
-            Hit h[PW]; int ret[PW]; Note note[PW];
+            Hit h[PW]; int ret[PW], suspect[PW]; Note note[PW];
+            static _Thread_local Trace second[PW], resumed;
+            for (int l = 0; l < PW; l++) second[l].cnt = 0;
             for (int l = 0; l < PW; l++) { h[l].tmin = FLT_MAX; h[l].m = h[l].t = -1; h[l].u = h[l].v = 0; }
-            packet_search(s, rays, live, sa, ca, h, ret, note, &ps, cull);
+            packet_search(s, rays, live, sa, ca, h, ret, note, suspect, second, &ps, cull);
             for (int l = 0; l < PW; l++) if (live >> l & 1) {
                 Hit a; Note na; Cnt c; memset(&c, 0, sizeof c);
                 a.tmin = FLT_MAX; a.m = a.t = -1; a.u = a.v = 0;
@@ -297,7 +417,30 @@ void packet_check(const Scene *s, const double eye[3], double angle, double zoom
                 ps.ref_node_visits += c.node_visits; ps.ref_tri_tests += c.tri_tests;
                 n_rays++;
                 if (fa != ret[l] || memcmp(&a, &h[l], sizeof a) != 0) n_diff++;
-                if (fb != fa || na.far_max != note[l].far_max || na.stack_min != note[l].stack_min) n_note++;
+                /* the second search of mainOMP.cpp:60 as written, against what the packet walk says about it */
+                int again = 0, found2 = 0;
+                if (fa) {
+                    Hit a2 = a; Cnt c2; memset(&c2, 0, sizeof c2);
+                    a2.m = a2.t = -1; a2.u = a2.v = 0;                      /* the bound stays: the first hit's distance */
+                    found2 = search_ref(s, &rays[l], &a2, &c2);
+                    again = note[l].far_max > a.tmin || suspect[l];
+                    ps.n_again += again; ps.n_again_old += na.far_max > a.tmin || na.stack_min < a.tmin; ps.n_found2 += found2;
+                }
+                if (fb != fa || na.far_max != note[l].far_max || (found2 && !again)) n_note++;
+                /* structure: whenever no far-only step lay beyond the hit, the second search as written ends with exactly the
+                   walk that resumes from the first search's stack, and the packet walk made that very walk for this ray */
+                if (fa && !(na.far_max > a.tmin)) {
+                    int rret = 0;
+                    const int st = second_search_structure(s, &rays[l], &resumed, &rret);
+                    if (st == -1) { /* the hit came from an interior node only: nothing to resume */ }
+                    else if (st != 0) n_note++;
+                    if (st >= 0 && ret[l] && (h[l].m >= 0)) {
+                        int same = resumed.cnt == second[l].cnt && (rret == 2) == (suspect[l] != 0);
+                        for (int i = 0; same && i < resumed.cnt && i < TRACE_MAX; i++) same = resumed.n[i] == second[l].n[i];
+                        ps.n_resumed_nodes += resumed.cnt;
+                        if (!same) n_note++;
+                    }
+                }
             }
         }
 #pragma omp critical

@@ -4,7 +4,12 @@ oracle's own search, bit for bit.  A triangle that the packet test leaves out al
 would show up as a differing ray, so `differ == 0` is also the statement that the test never rejects wrongly.  The
 device evaluates the test in fp32 on per-view tables with a margin of 1e-5; the checker also evaluates it in fp64 with
 the margin of 1e-12 that the proof in pt_packet.h is written for and counts the triangles only the fp32 form leaves
-out (`loose`, must be 0): the fp32 form is the weaker test."""
+out (`loose`, must be 0): the fp32 form is the weaker test.
+For mainOMP.cpp:60 the walk goes on, for a ray that has its hit, with what is left of the second search (the entries its
+first search left on the stack).  The checker runs the second search as written for every ray and demands (a) that it
+finds nothing whenever the walk says it need not be run, and (b), ray by ray, that it is the first search's walk thinned
+out followed by exactly the nodes of the resumed walk, which are exactly the nodes the packet walk visited for that ray
+in its second state."""
 import ctypes as C
 import os
 import subprocess
@@ -14,7 +19,7 @@ import pytest
 
 from conftest import ROOT, sanitizer_flags, scene_path
 
-NAMES = "packets rays node_visits lists list_entries survivors lane_tests any_pass pushes pops max_depth ref_nodes ref_tris loose kept64".split()
+NAMES = "packets rays node_visits lists list_entries survivors lane_tests any_pass pushes pops max_depth ref_nodes ref_tris loose kept64 again again_old found2 resumed_nodes".split()
 
 
 @pytest.fixture(scope="module")
@@ -78,10 +83,13 @@ def test_packet_search_is_the_reference_search_for_every_camera_ray(checker, tmp
     p = agg["packets"]
     print(name, f"{total} rays in {p} packets; per packet: {agg['node_visits'] / p:.1f} nodes, {agg['list_entries'] / p:.1f} list entries, "
           f"{agg['survivors'] / p:.1f} kept by the packet test ({agg['kept64'] / p:.1f} by its fp64 form), {agg['any_pass'] / p:.1f} hit by some ray; deepest stack {agg['max_depth']}; "
-          f"per ray alone: {agg['ref_nodes'] / total:.1f} nodes, {agg['ref_tris'] / total:.1f} triangles")
+          f"per ray alone: {agg['ref_nodes'] / total:.1f} nodes, {agg['ref_tris'] / total:.1f} triangles; second search of mainOMP.cpp:60: to be run for "
+          f"{agg['again']} rays ({agg['again_old']} by the stack note alone), finds something for {agg['found2']}; resumed walks {agg['resumed_nodes']} nodes in all")
     assert total > 100000
     # the packet test pays: it keeps a small part of the list entries
     assert agg["survivors"] < agg["list_entries"] / 3
+    # resuming the second search inside the walk leaves fewer rays to search again than the note of the stack's entries did
+    assert agg["again"] <= agg["again_old"]
 
 
 def test_packet_test_off_changes_nothing(checker):
