@@ -38,9 +38,9 @@ enum { PT_MODEL_MAIN = 0,     /* main.cpp:41-147   (shadow rays, 4 GI samples)  
 /* Arithmetic of the GI sample rays.  Primary, mirror and their shadow rays are
    always traced in fp64 with the reference's operation order. */
 enum { PT_GI_F64_EXACT = 0,   /* fp64, reference search semantics, bit-reproducible */
-       PT_GI_F32_FAST = 1 };  /* fp32 wavefront queues, nearest-hit kd traversal; with PT_MODEL_MAIN
-                                 at most 32 lights (a shadow-ray queue entry per point and light):
-                                 more are refused with PT_ERR_LIMIT */
+       PT_GI_F32_FAST = 1 };  /* fp32 wavefront queues, nearest-hit kd traversal; with PT_MODEL_MAIN a
+                                 shadow-ray queue entry per point and light in front of it (any number
+                                 of lights; passes shrink past 16 so that the queue stays below 2^30) */
 
 /* One kd-tree node as built by the host (util/kdtree.cpp:74-82), flattened:
    children are adjacent (right == left + 1). */

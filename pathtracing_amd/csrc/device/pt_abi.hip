@@ -595,8 +595,6 @@ int ensure_workspace(PtScene *sc, int size, int batch, bool fast, int nsub, bool
     Workspace &ws = sc->ws;
     bool have_fast = ws.Q[0].rays_o != nullptr;
     shadow = shadow && fast;
-    if (shadow && sc->S.n_light > 32)
-        return fail(PT_ERR_LIMIT, "the fp32 GI path of the main.cpp model handles at most 32 lights (use gi_precision = exact)");
     if (ws.size == size && ws.batch >= batch && (!fast || have_fast) && ws.nsub >= nsub && (!shadow || ws.shadow)) return PT_OK;
     if (ws.size == size) {
         if (batch < ws.batch) batch = ws.batch;

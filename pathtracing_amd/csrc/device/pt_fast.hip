@@ -503,27 +503,31 @@ __global__ void __launch_bounds__(PT_APPEND_BLOCK) k_shade_gi(DevScene S, FastBu
     if (MODEL == PT_MODEL_MAIN) {
         // The shadow rays of the point, one per light that can add something (shadow_ray_wanted), are made here, where every
         // lane has a point, and queued one after the other in light order; the any-hit kernel is then a plain ray query.
-        uint32_t want = 0;                                     // bit k: light k gets a ray
+        // Which lights get a ray: a bit per light while there are at most 32 of them; with more, a count, and every stage that
+        // needs to know which ones asks shadow_ray_wanted again (the same arithmetic on the same numbers gives the same answer).
+        const bool masked = S.n_light <= 32;
+        uint32_t want = 0, nwant = 0;                          // bit k: light k gets a ray | how many do
         float4 one = make_float4(0.f, 0.f, 0.f, 0.f);          // direction and length of the newest ray
         if (hit)
             for (int k = 0; k < S.n_light; k++) {
                 float lx, ly, lz, dis;
-                if (shadow_ray_wanted(S, k, sp_pos, sp_nrm, lx, ly, lz, dis)) { want |= 1u << k; one = make_float4(lx, ly, lz, dis); }
+                if (shadow_ray_wanted(S, k, sp_pos, sp_nrm, lx, ly, lz, dis)) { if (masked) want |= 1u << k; nwant++; one = make_float4(lx, ly, lz, dis); }
             }
         const uint32_t q = block_append(hit, &Q.counts[1]);
-        uint32_t sq = block_append_n((uint32_t)__popc(want), &Q.counts[2]);
+        uint32_t sq = block_append_n(nwant, &Q.counts[2]);
         if (hit) {
-            // the point's record: position | lights with a ray, normal | queue index of the GI ray, base colour | first shadow ray
-            Q.sp_pos[q] = make_float4(sp_pos.x, sp_pos.y, sp_pos.z, __uint_as_float(want));
+            // the point's record: position | lights with a ray (more than 32 lights: the point's triangle), normal | queue index
+            // of the GI ray, base colour | first shadow ray
+            Q.sp_pos[q] = make_float4(sp_pos.x, sp_pos.y, sp_pos.z, masked ? __uint_as_float(want) : sp_pos.w);
             Q.sp_nrm[q] = sp_nrm;
             Q.sp_base[q] = make_float4(sp_base.x, sp_base.y, sp_base.z, __uint_as_float(sq));
-            if (__popc(want) == 1) {                            // the usual case: the one ray is still in registers
+            if (nwant == 1) {                                   // the usual case: the one ray is still in registers
                 Q.sh_o[sq] = sp_pos; Q.sh_d[sq] = one;
-            } else {
+            } else if (nwant) {
                 for (int k = 0; k < S.n_light; k++) {
-                    if (!((want >> k) & 1u)) continue;
                     float lx, ly, lz, dis;
-                    shadow_ray_wanted(S, k, sp_pos, sp_nrm, lx, ly, lz, dis);
+                    if (masked ? !((want >> k) & 1u) : !shadow_ray_wanted(S, k, sp_pos, sp_nrm, lx, ly, lz, dis)) continue;
+                    if (masked) shadow_ray_wanted(S, k, sp_pos, sp_nrm, lx, ly, lz, dis);
                     Q.sh_o[sq] = sp_pos;
                     Q.sh_d[sq] = make_float4(lx, ly, lz, dis);
                     sq++;
@@ -572,14 +576,25 @@ __global__ void __launch_bounds__(256) k_light_sum(DevScene S, FastBuffers Q) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= Q.counts[1]) return;
     const float4 pos = Q.sp_pos[p], nrm = Q.sp_nrm[p], base = Q.sp_base[p];
-    uint32_t want = __float_as_uint(pos.w), sq = __float_as_uint(base.w);
+    uint32_t sq = __float_as_uint(base.w);
     float dr = 0.f, dg = 0.f, db = 0.f;
-    for (; want; want &= want - 1u, sq++) {
-        if (Q.sh_d[sq].w == 0.0f) continue;                     // something lies between the point and the light
+    auto add_light = [&](int k) {
         float lx, ly, lz, dis, sr, sg, sb;
-        light_f(S.lightsF, __ffs((int)want) - 1, pos.x, pos.y, pos.z, lx, ly, lz, dis, sr, sg, sb);
+        light_f(S.lightsF, k, pos.x, pos.y, pos.z, lx, ly, lz, dis, sr, sg, sb);
         const float c = lx * nrm.x + ly * nrm.y + lz * nrm.z;
         dr += __fmul_rn(c, sr); dg += __fmul_rn(c, sg); db += __fmul_rn(c, sb);
+    };
+    if (S.n_light <= 32) {
+        for (uint32_t want = __float_as_uint(pos.w); want; want &= want - 1u, sq++)
+            if (Q.sh_d[sq].w != 0.0f) add_light(__ffs((int)want) - 1);      // 0: something lies between the point and the light
+    } else {
+        // more lights than a mask holds: which of them got a ray is asked again, as k_shade_gi asked (pos.w is the point's triangle)
+        for (int k = 0; k < S.n_light; k++) {
+            float lx, ly, lz, dis;
+            if (!shadow_ray_wanted(S, k, pos, nrm, lx, ly, lz, dis)) continue;
+            if (Q.sh_d[sq].w != 0.0f) add_light(k);
+            sq++;
+        }
     }
     Q.contrib[__float_as_uint(nrm.w)] = make_float4(base.x * dr, base.y * dg, base.z * db, 0.f);
 }
@@ -804,7 +819,7 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         const FastBuffers &Q = QQ[pass & 1];
         const int s0 = pass * batch, nb = nsamples - s0 < batch ? nsamples - s0 : batch;
         if ((size_t)nb * P > Q.max_rays) return PT_ERR_LIMIT;
-        if (V.model == PT_MODEL_MAIN && (!Q.sh_o || S.n_light > 32)) return PT_ERR_LIMIT;     // the shadow-ray queue was not asked for
+        if (V.model == PT_MODEL_MAIN && !Q.sh_o) return PT_ERR_LIMIT;     // the shadow-ray queue was not asked for
         if (pass + 1 < npass)
             if (int rc = generate(pass + 1)) return rc;
         unsigned sblocks = (unsigned)((P * nb + PT_APPEND_BLOCK - 1) / PT_APPEND_BLOCK);

@@ -364,8 +364,8 @@ def test_fast_gi_with_several_lights(host_scenes):
     """The fp32 GI path of the main.cpp model queues one shadow ray per shading point and light that can add something and
     sums the lights of a point in order afterwards.  cbox with five lights around its own (two of them on the far side
     of most surfaces): the image stays as close to the fp64 path's as with one light, run to run it is the same bit for
-    bit.  More than 32 lights are refused by that
-    path with a limit error, not rendered wrongly; the fp64 path takes them."""
+    bit.  Up to 32 lights the stages tell each other which lights got a ray with a bit per light; with more, each stage asks again
+    (33 and 70 lights: the same agreement with the fp64 path, the same ray counts run to run)."""
     from pathtracing_amd import host
     hs = host_scenes("cbox")
     d = hs.desc()
@@ -420,14 +420,22 @@ def test_fast_gi_with_several_lights(host_scenes):
         b = sc.render(**c, **kw, gi_precision=device.GI_F32_FAST)
         assert np.array_equal(a["rgb"], b["rgb"]) and b["stats"]["shadow"] == 0
         sc.close()
-        arr = with_lights(33)
-        d.lights, d.n_light = arr, 33
-        sc = device.DeviceScene(d)
-        with pytest.raises(device.DeviceError, match="32 lights"):
-            sc.render(**c, model=device.MODEL_MAIN, gi=True, spp=2, size=32, gi_precision=device.GI_F32_FAST)
-        sc.render(**c, model=device.MODEL_MAIN, gi=True, spp=1, size=16, gi_precision=device.GI_F64_EXACT)
-        sc.render(**c, model=device.MODEL_OMP, gi=True, spp=2, size=32, gi_precision=device.GI_F32_FAST)
-        sc.close()
+        for n in (33, 70):                                           # beyond the mask: no limit
+            arr = with_lights(n)
+            d.lights, d.n_light = arr, n
+            sc = device.DeviceScene(d)
+            kw = dict(model=device.MODEL_MAIN, gi=True, spp=2, size=48)
+            a = sc.render(**c, **kw, gi_precision=device.GI_F64_EXACT)
+            b = sc.render(**c, **kw, gi_precision=device.GI_F32_FAST)
+            b2 = sc.render(**c, **kw, gi_precision=device.GI_F32_FAST)
+            assert np.array_equal(b["rgb"], b2["rgb"]) and b["stats"]["shadow"] == b2["stats"]["shadow"]
+            diff = a["rgb"] - b["rgb"]
+            outlier = np.abs(diff).max(axis=2) > 0.03
+            assert outlier.sum() <= 5, (n, int(outlier.sum()))
+            assert float(np.sqrt(np.mean(diff[~outlier] ** 2))) < 2e-3, n
+            assert 0.7 * a["stats"]["shadow"] < b["stats"]["shadow"] <= a["stats"]["shadow"]
+            sc.render(**c, model=device.MODEL_OMP, gi=True, spp=2, size=32, gi_precision=device.GI_F32_FAST)
+            sc.close()
     finally:
         d.lights, d.n_light = keep
 
