@@ -71,7 +71,7 @@ struct Workspace {
 // Header of a scene slab (the one device allocation that holds every immutable array of a scene).
 #define PT_SLAB_MAX_ARRAYS 32
 struct SlabHeader {
-    char magic[8];                    // "PTSLAB03"
+    char magic[8];                    // "PTSLAB04"
     uint64_t total_bytes;             // header + arrays
     uint64_t array_bytes[PT_SLAB_MAX_ARRAYS];   // size of each array, in the order of PT_SLAB_POINTERS
     uint64_t body_check;              // slab_body_check() of everything after the header
@@ -380,7 +380,13 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
     B.add(d->tri_local, (size_t)d->n_tri, &DevScene::tri_local);
     B.add(d->norm, (size_t)d->n_norm * 3, &DevScene::norm);
     {
-        std::vector<float4> sh((size_t)d->n_tri * 5);
+        // the fp32 shading record: mesh and texture mode share one word (see DevScene::triShadeF)
+        int tex_bits = 1;
+        while ((1u << tex_bits) < 2u * d->n_tex + 1u) tex_bits++;
+        if (tex_bits > 24 || (uint64_t)d->n_mesh >= (1ull << (31 - tex_bits)))
+            return fail(PT_ERR_LIMIT, "more meshes and textures than the fp32 shading record has bits for");
+        S.n_tex = (int32_t)d->n_tex; S.tex_bits = tex_bits;
+        std::vector<float4> sh((size_t)d->n_tri * 4);
         for (uint32_t t = 0; t < d->n_tri; t++) {
             float n[9], uv[6];
             for (int c = 0; c < 3; c++) {
@@ -390,15 +396,27 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
                 uv[2 * c] = ui >= 0 ? (float)d->uv[2 * (size_t)ui] : 0.f;
                 uv[2 * c + 1] = ui >= 0 ? (float)d->uv[2 * (size_t)ui + 1] : 0.f;
             }
-            const double *al = d->mesh_albedo + 3 * (size_t)d->tri_mesh[t];
-            float4 *o = &sh[(size_t)t * 5];
+            const int32_t tm = d->tri_tm[t];
+            const uint32_t mode = tm == -99999 ? 0u : (tm >= 0 ? 1u + (uint32_t)tm : 1u + d->n_tex + (uint32_t)(-(tm + 1)));
+            const uint32_t code = (uint32_t)d->tri_mesh[t] << tex_bits | mode;
+            float4 *o = &sh[(size_t)t * 4];
             o[0] = make_float4(n[0], n[1], n[2], n[3]);
             o[1] = make_float4(n[4], n[5], n[6], n[7]);
             o[2] = make_float4(n[8], uv[0], uv[1], uv[2]);
-            o[3] = make_float4(uv[3], uv[4], uv[5], bits_to_float(d->tri_tm[t]));
-            o[4] = make_float4((float)al[0], (float)al[1], (float)al[2], 0.f);
+            o[3] = make_float4(uv[3], uv[4], uv[5], bits_to_float((int32_t)code));
         }
         B.add(sh.data(), sh.size(), &DevScene::triShadeF);
+        std::vector<float4> alb(d->n_mesh);
+        for (uint32_t m = 0; m < d->n_mesh; m++)
+            alb[m] = make_float4((float)d->mesh_albedo[3 * (size_t)m], (float)d->mesh_albedo[3 * (size_t)m + 1], (float)d->mesh_albedo[3 * (size_t)m + 2], 0.f);
+        B.add(alb.data(), alb.size(), &DevScene::meshAlbF);
+        if (texels.size() / 3 >= (1ull << 31)) return fail(PT_ERR_LIMIT, "more than 2^31 texels");
+        std::vector<int4> tf(d->n_tex);
+        std::vector<uint32_t> t4(texels.size() / 3);
+        for (uint32_t k = 0; k < d->n_tex; k++) tf[k] = make_int4(trows[k], tcols[k], (int)(toff[k] / 3), 0);
+        for (size_t k = 0; k < t4.size(); k++) t4[k] = (uint32_t)texels[3 * k] | (uint32_t)texels[3 * k + 1] << 8 | (uint32_t)texels[3 * k + 2] << 16;
+        B.add(tf.data(), tf.size(), &DevScene::texF);
+        B.add(t4.data(), t4.size(), &DevScene::texels4);
     }
     B.add(d->uv, (size_t)d->n_uv * 2, &DevScene::uv);
     B.add(d->mesh_albedo, (size_t)d->n_mesh * 3, &DevScene::albedo);
@@ -431,7 +449,7 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
     if (const char *e = getenv("PT_TUNE_OVF_DEPTH")) { int k = atoi(e); if (k >= 1 && (uint32_t)k < S.ovf_depth) S.ovf_depth = (uint32_t)k; }
     S.ovf_waves = PT_TRACE_WAVES;
     S.ovf64_entries = (uint32_t)depth + 2u;
-    std::memcpy(H.magic, "PTSLAB03", 8);
+    std::memcpy(H.magic, "PTSLAB04", 8);
     H.total_bytes = B.bytes.size();
     {
         size_t k = 0;
@@ -450,7 +468,7 @@ int build_slab(const PtSceneDesc *d, SlabBuilder &B) {
 // the `bytes` of the block and have the sizes the kernels will assume from the scene's counts?  (What is IN the arrays --
 // node links, triangle offsets, indices -- is covered by the body checksum, compared once the block is on the device.)
 int check_slab_header(const SlabHeader &H, size_t bytes) {
-    if (std::memcmp(H.magic, "PTSLAB03", 8) != 0 || H.total_bytes != bytes || bytes < kSlabBody || (bytes & 7) || H.check != header_check(H))
+    if (std::memcmp(H.magic, "PTSLAB04", 8) != 0 || H.total_bytes != bytes || bytes < kSlabBody || (bytes & 7) || H.check != header_check(H))
         return fail(PT_ERR_INVALID, "not a scene slab of this library version, or damaged");
     const DevScene &S = H.S;
     if (S.n_node < 1 || S.n_ref < 0 || S.n_tri < 0 || S.n_light < 0 || (uint64_t)S.n_tri != H.n_tri)
@@ -477,12 +495,14 @@ int check_slab_header(const SlabHeader &H, size_t bytes) {
         {have[i_refId], nr * 4, "refId"}, {have[i_nodeF], H.refine.nodes * sizeof(NodeF), "nodeF"}, {have[i_refTriF], H.refine.refs * 48, "refTriF"},
         {have[i_triGeo], nt * 72, "triGeo"}, {have[i_triNgF], nt * 16, "triNgF"}, {have[i_tri_ni], nt * 12, "tri_ni"}, {have[i_tri_ti], nt * 12, "tri_ti"},
         {have[i_tri_tm], nt * 4, "tri_tm"}, {have[i_tri_reft], nt * 4, "tri_reft"}, {have[i_tri_mesh], nt * 4, "tri_mesh"},
-        {have[i_tri_local], nt * 4, "tri_local"}, {have[i_triShadeF], nt * 80, "triShadeF"}, {have[i_albedo], (uint64_t)H.n_mesh * 24, "albedo"},
+        {have[i_tri_local], nt * 4, "tri_local"}, {have[i_triShadeF], nt * 64, "triShadeF"}, {have[i_meshAlbF], (uint64_t)H.n_mesh * 16, "meshAlbF"}, {have[i_albedo], (uint64_t)H.n_mesh * 24, "albedo"},
         {have[i_lights], nl * sizeof(PtLight), "lights"}, {have[i_lightsF], nl * 32, "lightsF"},
     };
     for (const Want &w : wants)
         if (w.have != w.want) return fail(PT_ERR_INVALID, std::string("scene slab: array ") + w.what + " does not have the size its count asks for");
-    if (have[i_tex_off] / 8 != have[i_tex_rows] / 4 || have[i_tex_rows] != have[i_tex_cols] || (S.has_quads && have[i_quadF] < 16))
+    if (have[i_tex_off] / 8 != have[i_tex_rows] / 4 || have[i_tex_rows] != have[i_tex_cols] || (S.has_quads && have[i_quadF] < 16) ||
+        S.n_tex < 0 || have[i_tex_rows] != (uint64_t)S.n_tex * 4 || have[i_texF] != (uint64_t)S.n_tex * 16 || have[i_texels4] / 4 != have[i_texels] / 3 ||
+        S.tex_bits < 1 || S.tex_bits > 24 || (1ull << S.tex_bits) < 2ull * (uint64_t)S.n_tex + 1ull || H.n_mesh >= (1ull << (31 - S.tex_bits)))
         return fail(PT_ERR_INVALID, "scene slab: texture or quad tables inconsistent");
     // scratch every copy allocates from these: keep them in the range build_slab can produce
     if (S.ovf_waves != PT_TRACE_WAVES || S.ovf_depth < 1 || S.ovf_depth > 4096 || S.ovf64_entries < 2 || S.ovf64_entries > PT_STACK_MAX + 2 ||

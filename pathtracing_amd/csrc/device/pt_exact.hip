@@ -97,6 +97,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_
     extern __shared__ double stack_lds[];
     const uint32_t lane = threadIdx.x & 63;
     uint32_t nprimary = 0;
+    PktClk C;
+    C.reset();
     // persistent waves: a launched block (it owns a region of the stack overflow buffer) draws work blocks from a counter
     for (;;) {
         const PrimaryArgsU a0 = primary_args();
@@ -118,8 +120,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_
         HitD h;
         h.tmin = (double)FLT_MAX; h.tri = -1; h.u = 0; h.v = 0;
         SearchNote note;
-        const bool ok = MODEL == PT_MODEL_OMP ? packet_search<true>(A.S, ray, live, PB, A.B.forms, h, &note, stack_lds)
-                                              : packet_search<false>(A.S, ray, live, PB, A.B.forms, h, nullptr, stack_lds);
+        const bool ok = MODEL == PT_MODEL_OMP ? packet_search<true>(A.S, ray, live, PB, A.B.forms, h, &note, stack_lds, C)
+                                              : packet_search<false>(A.S, ray, live, PB, A.B.forms, h, nullptr, stack_lds, C);
         const PrimaryArgsU a1 = primary_args();
         const int size = a1->V.size, rb = a1->V.rb;
         const size_t p = (size_t)i * size + j, slot = rb ? p * 9 + sub : p;
@@ -139,7 +141,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_
         double *tuv = a1->B.tuv + 3 * slot;
         tuv[0] = ok ? h.tmin : -1.0; tuv[1] = h.u; tuv[2] = h.v;
         a1->B.again[slot] = again ? 1 : 0;
+        C.lap(5);
     }
+    C.flush();
     const uint32_t total = wave_sum(nprimary);
     if (lane == 0 && total) atomicAdd(&primary_args()->F.counters[RC_PRIMARY], (unsigned long long)total);
 }
@@ -479,6 +483,18 @@ int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F,
         static const unsigned ws = resident_waves(k_primary_search<PT_MODEL_OMP>, PT_EXACT_WAVES, PT_PKT_LDS_BYTES), wm = resident_waves(k_mirror_exact<PT_MODEL_OMP>, PT_EXACT_WAVES);
         const size_t slots = P * (V.rb ? 9 : 1);
         hipLaunchKernelGGL(k_primary_search<PT_MODEL_OMP>, dim3(pblocks < ws ? pblocks : ws), dim3(64), PT_PKT_LDS_BYTES, s, PA);
+#ifdef PT_PKT_CLOCKS
+        {   // instrumented build: wave clocks per part of the walk, summed over the launch
+            unsigned long long c[16];
+            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(c, HIP_SYMBOL(g_pkt_clk), sizeof c) == hipSuccess) {
+                fprintf(stderr, "pkt_clk");
+                for (int k = 0; k < 6; k++) fprintf(stderr, " %llu/%llu", c[k], c[8 + k]);
+                fprintf(stderr, "\n");
+                for (int k = 0; k < 16; k++) c[k] = 0;
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pkt_clk), c, sizeof c);
+            }
+        }
+#endif
         const size_t sblocks = (slots + 255) / 256;
         // The listed sub-rays (few; the list's length is on the device) run on the second stream beside the shading of the others:
         // a handful of waves that each make a whole search alone are latency, not load, and the two kernels write different sub-rays.

@@ -182,6 +182,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(FastBuffers Q, int tiles) {
 // direction cell (counting sort in LDS), so that the 64 rays a wave of the closest-hit kernel
 // draws together start close to each other and point the same way.  Queue order inside the block is
 // free: the ray's code, (sample of the pass) * 64 + (pixel of the tile), travels with it.
+#define PT_GEN_THREADS 1024                         // threads of a generator block (PT_TUNE_GEN_THREADS: 512 or 1024)
 #define PT_GEN_CELL_BITS 6                          // direction cells per axis of the octahedral map = 1 << bits
 #define PT_GEN_BINS (1 << (2 * PT_GEN_CELL_BITS))
 __device__ __forceinline__ uint32_t dir_bin(float x, float y, float z) {
@@ -203,17 +204,19 @@ __device__ __forceinline__ uint32_t dir_bin(float x, float y, float z) {
 }
 static_assert(PT_GEN_CELL_BITS <= 8, "the bit interleave of dir_bin handles 8 bits per coordinate");
 
-__global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, FrameBuffers F, FastBuffers Q, int s0, int nb, int groups) {
-    __shared__ uint32_t hist[PT_GEN_BINS];
-    __shared__ uint32_t bin_base[PT_GEN_BINS];
-    __shared__ uint32_t block_base, wave_sum[16];
+// T threads per block (1 024 or 512): a block takes one tile of 64 pixels and 4 * T / 64 samples of each -- four per thread.
+template <int T>
+__global__ void __launch_bounds__(T) k_gi_gen(DevScene S, ViewParams V, FrameBuffers F, FastBuffers Q, int s0, int nb, int groups) {
+    constexpr int WAVES = T / 64, SPB = 4 * WAVES, RAYS = 64 * SPB;      // samples per pixel and rays of a block
+    __shared__ uint32_t hist[PT_GEN_BINS];                   // rays per direction cell, then (in place) the cell's first place in the block's run
+    __shared__ uint32_t block_base, wave_sum[WAVES];
     const int tid = threadIdx.x;
     const int qtile = blockIdx.x / groups, group = blockIdx.x - qtile * groups;
     const int tile = ordered_tile(qtile, V.size);
     int i, j;
     const bool live = tile_pixel_f(tile * 64 + (tid & 63), V.size, i, j);
     const size_t p = live ? (size_t)i * V.size + j : 0;
-    for (int k = tid; k < PT_GEN_BINS; k += 1024) hist[k] = 0;
+    for (int k = tid; k < PT_GEN_BINS; k += T) hist[k] = 0;
     __syncthreads();
     bool pix_valid = false;
     float4 ro = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
     uint32_t key[4], rank[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int sl = group * 64 + r * 16 + (tid >> 6);
+        const int sl = group * SPB + r * WAVES + (tid >> 6);
         key[r] = 0xFFFFFFFFu;
         if (live && sl < nb) {
             if (pix_valid) {
@@ -264,11 +267,12 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
     __syncthreads();
     uint32_t in_block;                                       // rays of the block
     {
-        // exclusive prefix sum of the histogram: a run of bins per thread, a scan per wave, a scan over the 16 waves
-        constexpr int RUN = (PT_GEN_BINS + 1023) / 1024;
+        // exclusive prefix sum of the histogram, in place: a run of bins per thread, a scan per wave, a scan over the waves
+        constexpr int RUN = (PT_GEN_BINS + T - 1) / T;
         const int lane = tid & 63, wave = tid >> 6, first = tid * RUN;
-        uint32_t local = 0;
-        for (int k = 0; k < RUN; k++) local += first + k < PT_GEN_BINS ? hist[first + k] : 0u;
+        uint32_t mine[RUN], local = 0;
+#pragma unroll
+        for (int k = 0; k < RUN; k++) { mine[k] = first + k < PT_GEN_BINS ? hist[first + k] : 0u; local += mine[k]; }
         uint32_t incl = local;
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t nbr = __shfl_up(incl, o, 64);
@@ -277,14 +281,15 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
         if (lane == 63) wave_sum[wave] = incl;
         __syncthreads();
         uint32_t before = 0, total = 0;
-        for (int w = 0; w < 16; w++) { before += w < wave ? wave_sum[w] : 0u; total += wave_sum[w]; }
+        for (int w = 0; w < WAVES; w++) { before += w < wave ? wave_sum[w] : 0u; total += wave_sum[w]; }
         uint32_t run = before + incl - local;
+#pragma unroll
         for (int k = 0; k < RUN; k++)
-            if (first + k < PT_GEN_BINS) { bin_base[first + k] = run; run += hist[first + k]; }
+            if (first + k < PT_GEN_BINS) { hist[first + k] = run; run += mine[k]; }
         // the block's place in the queue is fixed: tiles in queue order, the sample groups of a tile one after another
         if (tid == 0) {
             const uint32_t t0 = Q.tile_base[qtile], valid = Q.tile_base[qtile + 1] - t0;
-            const uint32_t done_samples = (uint32_t)(group * 64 < nb ? group * 64 : nb);
+            const uint32_t done_samples = (uint32_t)(group * SPB < nb ? group * SPB : nb);
             block_base = t0 * (uint32_t)nb + valid * done_samples;
             if (blockIdx.x == 0) Q.counts[0] = Q.tile_base[gridDim.x / groups] * (uint32_t)nb;
         }
@@ -294,29 +299,29 @@ __global__ void __launch_bounds__(1024) k_gi_gen(DevScene S, ViewParams V, Frame
     // The sorted order is made in LDS -- every ray's direction and code dropped at its place in the block's run -- and the
     // run then leaves for the queue in whole lines: written straight from the threads, 16 bytes each at a random place
     // of the run, the three arrays cost 0.3 ms more per 67 M rays.  The origin is the pixel's, found through the code.
-    extern __shared__ float4 staged[];                       // 4096 directions, 64 origins, 4096 codes
-    float4 *stage_d = staged, *stage_o = staged + 4096;
-    uint32_t *stage_c = (uint32_t *)(staged + 4096 + 64);
+    extern __shared__ float4 staged[];                       // RAYS directions, 64 origins, RAYS codes
+    float4 *stage_d = staged, *stage_o = staged + RAYS;
+    uint32_t *stage_c = (uint32_t *)(staged + RAYS + 64);
     if (tid < 64) stage_o[tid] = ro;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         if (key[r] != 0xFFFFFFFFu) {
-            const int sl = group * 64 + r * 16 + (tid >> 6);
-            const uint32_t at = bin_base[key[r]] + rank[r];
+            const int sl = group * SPB + r * WAVES + (tid >> 6);
+            const uint32_t at = hist[key[r]] + rank[r];
             stage_d[at] = rd[r];
             stage_c[at] = (uint32_t)sl * 64u + (uint32_t)(tid & 63);
             if (__float_as_uint(rd[r].w) >> 31) Q.hits[block_base + at] = make_float4(st[r], su[r], sv[r], __int_as_float(otri));
         }
     }
     __syncthreads();
-    for (uint32_t k = tid; k < in_block; k += 1024) {
+    for (uint32_t k = tid; k < in_block; k += T) {
         const uint32_t code = stage_c[k], q = block_base + k;
         Q.rays_o[q] = stage_o[code & 63u];
         Q.rays_d[q] = stage_d[k];
         Q.ray_slot[q] = code;
     }
 }
-#define PT_GEN_LDS_BYTES ((4096 + 64) * sizeof(float4) + 4096 * sizeof(uint32_t))
+#define PT_GEN_LDS_BYTES(T) ((size_t)((T) * 4 + 64) * sizeof(float4) + (size_t)(T) * 4 * sizeof(uint32_t))
 
 // ---- stage 2: closest hit -------------------------------------------------------
 // LS: LaneState (binary node records, pt_trace_f32.h) or LaneStateQ (quad records, pt_trace_quad.h); the same search.
@@ -364,43 +369,45 @@ __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q,
 struct SurfF { float nx, ny, nz, tr, tg, tb; };
 
 __device__ __forceinline__ int clampi_f(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ const uint8_t *texel_f(const DevScene &S, int tex, int px, int py) {
-    int rows = S.tex_rows[tex], cols = S.tex_cols[tex];
-    int row = clampi_f(py, 0, rows - 1), col = clampi_f(px, 0, cols - 1);
-    return S.texels + S.tex_off[tex] + ((size_t)row * cols + col) * 3;
+// texel (px, py) of the texture with table entry tm = (rows, cols, first texel), clamped as the reference's Mat::at is used
+__device__ __forceinline__ uint32_t texel_f(const DevScene &S, const int4 tm, int px, int py) {
+    const int row = clampi_f(py, 0, tm.x - 1), col = clampi_f(px, 0, tm.y - 1);
+    return S.texels4[(size_t)tm.z + (size_t)row * tm.y + col];
 }
 
 // surfaceProperties (util/polygonMesh.cpp:81-118) in fp32, from the packed per-triangle record.
 // Also returns the albedo of the triangle's mesh.
 __device__ __forceinline__ SurfF surface_f(const DevScene &S, int tri, float bu, float bv, float &ar, float &ag, float &ab) {
     SurfF o;
-    const float4 *R = S.triShadeF + (size_t)tri * 5;
-    const float4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
-    ar = r4.x; ag = r4.y; ab = r4.z;
+    const float4 *R = S.triShadeF + (size_t)tri * 4;
+    const float4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3];
+    const uint32_t code = __float_as_uint(r3.w), mode = code & ((1u << S.tex_bits) - 1u);
+    const float4 al = S.meshAlbF[code >> S.tex_bits];
+    ar = al.x; ag = al.y; ab = al.z;
     const float w = 1.0f - bu - bv;
     float nx = w * r0.x + bu * r0.w + bv * r1.z;
     float ny = w * r0.y + bu * r1.x + bv * r1.w;
     float nz = w * r0.z + bu * r1.y + bv * r2.x;
     float il = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
     o.nx = nx * il; o.ny = ny * il; o.nz = nz * il;
-    int mn = __float_as_int(r3.w);
-    if (mn == -99999) { o.tr = o.tg = o.tb = 1.0f; return o; }
+    if (mode == 0u) { o.tr = o.tg = o.tb = 1.0f; return o; }
     const float u0 = r2.y, v0 = r2.z, u1 = r2.w, v1 = r3.x, u2 = r3.y, v2 = r3.z;
-    if (mn < 0) {
-        mn = -(mn + 1);
-        float rows = (float)S.tex_rows[mn];
+    const bool at_hit = mode > (uint32_t)S.n_tex;
+    const int4 tm = S.texF[mode - 1u - (at_hit ? (uint32_t)S.n_tex : 0u)];
+    if (at_hit) {
+        const float rows = (float)tm.x;
         int r = (int)((u0 * w + u1 * bu + u2 * bv) * rows);
         int cc = (int)((v0 * w + v1 * bu + v2 * bv) * rows);
-        const uint8_t *p = texel_f(S, mn, r, cc);
-        o.tr = p[2] * (1.0f / 256.0f); o.tg = p[1] * (1.0f / 256.0f); o.tb = p[0] * (1.0f / 256.0f);
+        const uint32_t p = texel_f(S, tm, r, cc);
+        o.tr = (float)((p >> 16) & 255u) * (1.0f / 256.0f); o.tg = (float)((p >> 8) & 255u) * (1.0f / 256.0f); o.tb = (float)(p & 255u) * (1.0f / 256.0f);
     } else {
-        int rows = S.tex_rows[mn], cols = S.tex_cols[mn];
+        const float rows = (float)tm.x, cols = (float)tm.y;
         float cr = 0, cg = 0, cb = 0;
         const float wt[3] = {w, bu, bv}, uu[3] = {u0, u1, u2}, vv[3] = {v0, v1, v2};
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            const uint8_t *p = texel_f(S, mn, (int)(uu[i] * rows), (int)(vv[i] * cols));
-            cr += wt[i] * p[2]; cg += wt[i] * p[1]; cb += wt[i] * p[0];
+            const uint32_t p = texel_f(S, tm, (int)(uu[i] * rows), (int)(vv[i] * cols));
+            cr += wt[i] * (float)((p >> 16) & 255u); cg += wt[i] * (float)((p >> 8) & 255u); cb += wt[i] * (float)(p & 255u);
         }
         o.tr = cr * (1.0f / 256.0f); o.tg = cg * (1.0f / 256.0f); o.tb = cb * (1.0f / 256.0f);
     }
@@ -756,10 +763,11 @@ int fast_alloc(FastBuffers Q[2], size_t pixels, int batch, int n_light, PtAllocF
 // Launch parameters of the closest-hit kernel.  The defaults are what the
 // measurements in profiles/ were taken with; the PT_TUNE_* environment
 // variables exist for sweeps.
-struct TraceTune { int slots, refill, waves, chunk, gen_lds, shade_lds; };
+struct TraceTune { int slots, refill, waves, chunk, gen_lds, shade_lds, gen_threads; };
 static TraceTune trace_tune() {
     TraceTune t = [] {
-        TraceTune v{FS_SLOTS, PT_REFILL_MIN, PT_TRACE_WAVES, PT_QUEUE_CHUNK, 0, PT_SHADE_LDS_BYTES};
+        TraceTune v{FS_SLOTS, PT_REFILL_MIN, PT_TRACE_WAVES, PT_QUEUE_CHUNK, 0, PT_SHADE_LDS_BYTES, PT_GEN_THREADS};
+        if (const char *e = getenv("PT_TUNE_GEN_THREADS")) { int k = atoi(e); if (k == 512 || k == 1024) v.gen_threads = k; }
         if (const char *e = getenv("PT_TUNE_GEN_LDS")) { int k = atoi(e); if (k >= 0 && k <= 150000) v.gen_lds = k; }
         if (const char *e = getenv("PT_TUNE_SHADE_LDS")) { int k = atoi(e); if (k >= 0 && k <= 150000) v.shade_lds = k; }
         if (const char *e = getenv("PT_TUNE_SLOTS")) { int k = atoi(e); if (k == 2 || k == 4 || k == 8 || k == 16 || k == 32) v.slots = k; }
@@ -804,13 +812,16 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
     FQ(hipEventRecord(view_ready, s));
     auto generate = [&](int pass) -> int {
         const FastBuffers &Q = QQ[pass & 1];
-        const int s0 = pass * batch, nb = nsamples - s0 < batch ? nsamples - s0 : batch, groups = (nb + 63) / 64;
+        const int s0 = pass * batch, nb = nsamples - s0 < batch ? nsamples - s0 : batch, spb = tune.gen_threads / 16, groups = (nb + spb - 1) / spb;
         // the ray set is free once the pass before the previous one is done (pass 0 and 1: once the view is ready);
         // the generator then runs beside the start of the previous pass's traversal.  (Holding it back until that
         // traversal has ended, so that it runs beside the shading instead, was slower.)
         FQ(hipStreamWaitEvent(s_gen, pass >= 2 ? events[4 * (pass - 2) + 3] : view_ready, 0));
         FQ(hipMemsetAsync(Q.counts, 0, (PT_PASS_COUNT_WORDS + 2 * PT_HEAD_WORDS) * sizeof(uint32_t), s_gen));
-        hipLaunchKernelGGL(k_gi_gen, dim3((unsigned)((tthreads / 64) * groups)), dim3(1024), PT_GEN_LDS_BYTES + (size_t)tune.gen_lds, s_gen, S, V, F, Q, s0, nb, groups);
+        if (tune.gen_threads == 512)
+            hipLaunchKernelGGL(k_gi_gen<512>, dim3((unsigned)((tthreads / 64) * groups)), dim3(512), PT_GEN_LDS_BYTES(512) + (size_t)tune.gen_lds, s_gen, S, V, F, Q, s0, nb, groups);
+        else
+            hipLaunchKernelGGL(k_gi_gen<1024>, dim3((unsigned)((tthreads / 64) * groups)), dim3(1024), PT_GEN_LDS_BYTES(1024) + (size_t)tune.gen_lds, s_gen, S, V, F, Q, s0, nb, groups);
         FQ(hipEventRecord(events[4 * pass], s_gen));
         return PT_OK;
     };

@@ -25,14 +25,22 @@
 #define PT_PKT_WAVES 4                     // waves per SIMD the search kernel is compiled for
 #endif
 
-// PT_PKT_CLOCKS (an instrumented build for tools/pkt_clocks.py, never the product): wave clocks per part of the walk.
+// PT_PKT_CLOCKS (an instrumented build for tools/pkt_clocks.sh, never the product): wave clocks per part of the walk.
+// Slots: 0 pop, 1 node fetch, 2 packet test of a list, 3 triangle fetch + the reference's test, 4 the step to the
+// children, 5 everything else of a packet (set-up, results).
 #ifdef PT_PKT_CLOCKS
 __device__ unsigned long long g_pkt_clk[16];
-#define PKT_T0() unsigned long long pkt_t_ = __builtin_amdgcn_s_memtime()
-#define PKT_LAP(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pkt_acc_[slot] += n_ - pkt_t_; pkt_cnt_[slot]++; pkt_t_ = __builtin_amdgcn_s_memtime(); } while (0)
+struct PktClk {
+    unsigned long long acc[6], cnt[6], t;
+    PT_DEV void reset() { for (int k = 0; k < 6; k++) acc[k] = cnt[k] = 0; t = __builtin_amdgcn_s_memtime(); }
+    PT_DEV void lap(int slot) { const unsigned long long n = __builtin_amdgcn_s_memtime(); acc[slot] += n - t; cnt[slot]++; t = n; }
+    PT_DEV void flush() {
+        if ((threadIdx.x & 63u) == 0)
+            for (int k = 0; k < 6; k++) { atomicAdd(&g_pkt_clk[k], acc[k]); atomicAdd(&g_pkt_clk[8 + k], cnt[k]); }
+    }
+};
 #else
-#define PKT_T0() do {} while (0)
-#define PKT_LAP(slot) do {} while (0)
+struct PktClk { PT_DEV void reset() {} PT_DEV void lap(int) {} PT_DEV void flush() {} };
 #endif
 
 PT_DEV double wave_min_d(double v) {
@@ -228,7 +236,7 @@ PT_DEV PacketRay packet_ray(const RayD &r) {
 // second: this ray is in its second search (see packet_search): a triangle that would improve on the bound is reported, the
 // hit record stays as the first search left it.
 PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, const RayD &ray, bool in, bool second, const PacketBoundsF &B,
-                        const float4 *forms, HitD &h) {
+                        const float4 *forms, HitD &h, PktClk &C) {
     const uint32_t lane = threadIdx.x & 63u;
     bool improved = false;
     for (int base = 0; base < count0; base += 64) {
@@ -243,6 +251,7 @@ PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, co
             }
             surv = __ballot(keep);
         }
+        C.lap(2);
         if (!surv) continue;
         // the triangles that are left, one after the other for the whole wave; the next one is on its way while this one is tested
         int k = first0 + base + (int)__builtin_ctzll(surv);
@@ -268,6 +277,7 @@ PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, co
                     }
                 }
             }
+            C.lap(3);
             if (!more) break;
             if (!PT_PKT_PRE_TRI) {
                 k = first0 + base + (int)__builtin_ctzll(surv);
@@ -295,7 +305,7 @@ PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, co
 // as written is the first one's walk thinned out followed by exactly this resumed walk: on the atrium 1 095 of 6.2 M camera
 // rays left such entries, each resumed walk was 2 or 3 nodes long, none found anything.
 template <bool NOTED>
-PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, const PacketBoundsF &B, const float4 *forms, HitD &h, SearchNote *note, double *lds) {
+PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, const PacketBoundsF &B, const float4 *forms, HitD &h, SearchNote *note, double *lds, PktClk &C) {
     const uint32_t lane = threadIdx.x & 63u;
     const PacketRay pr = packet_ray(ray_in);
     const RayD ray = make_ray(d3(pr.ox, pr.oy, pr.oz), d3(pr.dx, pr.dy, pr.dz));
@@ -308,6 +318,7 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, cons
     bool found = false, at_leaf = false;
     unsigned long long act = __ballot(in);
     int curr = 0;
+    C.lap(5);
     // One loop with one back edge: a turn pops an entry if no ray is in the current node, and then, if some ray is in
     // the (new) current node, does that node.
     for (;;) {
@@ -328,12 +339,14 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, cons
                 }
             }
             act = __ballot(in);
+            C.lap(0);
         }
         if (act) {
             const NodeA nd = load_node_u(S, curr);
             const int axis = nd.axis, left = nd.left;
             bool improved = false;
-            if (nd.count > 0) improved = packet_node(S, curr, nd.first, nd.count, ray, in, NOTED && second, B, forms, h);
+            C.lap(1);
+            if (nd.count > 0) improved = packet_node(S, curr, nd.first, nd.count, ray, in, NOTED && second, B, forms, h, C);
             if (NOTED && in && second && improved) {    // the second search would find something: it has to be run as written
                 note->stack_min = -DBL_MAX;
                 second = false; in = false; improved = false;
@@ -370,6 +383,7 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, cons
                     st.sp = 0; act = 0; finished = true; second = false;
                 }
             }
+            C.lap(4);
         }
     }
     return at_leaf || found;

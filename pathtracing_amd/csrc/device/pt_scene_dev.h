@@ -54,10 +54,17 @@ struct DevScene {
     // ---- shading data ----
     const int32_t *tri_ni, *tri_ti, *tri_tm, *tri_reft, *tri_mesh, *tri_local;
     const double *norm, *uv, *albedo;
-    // GI fast path: everything surfaceProperties needs of a triangle in one 80-byte record (5 float4):
-    // n0.xyz n1.x | n1.yz n2.xy | n2.z uv0.xy uv1.x | uv1.y uv2.xy tm(int bits) | albedo.rgb of its mesh, 0
-    // (a missing uv index is stored as (0, 0), which is what the reference uses for it)
+    // GI fast path: everything surfaceProperties needs of a triangle in one 64-byte record (4 float4, four requests):
+    // n0.xyz n1.x | n1.yz n2.xy | n2.z uv0.xy uv1.x | uv1.y uv2.xy code
+    // (a missing uv index is stored as (0, 0), which is what the reference uses for it).  code = mesh << tex_bits | t with
+    // t = 0: no texture, 1 + k: texture k looked up at the three vertices, 1 + n_tex + k: texture k looked up at the hit.
+    // meshAlbF: albedo per mesh (rgb, 0).  texF: per texture (rows, cols, index of its first texel in texels4, 0);
+    // texels4: one word per texel, B | G << 8 | R << 16, so a texel is one request instead of three.
     const float4 *triShadeF;
+    const float4 *meshAlbF;
+    const int4 *texF;
+    const uint32_t *texels4;
+    int32_t n_tex, tex_bits;
     const uint8_t *texels;
     const int64_t *tex_off;
     const int32_t *tex_rows, *tex_cols;
@@ -79,7 +86,8 @@ struct DevScene {
 // own base address -- no host preprocessing, no second build of the fp32 tree.
 #define PT_SLAB_POINTERS(X) \
     X(nodeA) X(nodeBox) X(refTri) X(refId) X(nodeF) X(quadF) X(refTriF) X(triGeo) X(triNgF) X(tri_ni) X(tri_ti) X(tri_tm) X(tri_reft) \
-    X(tri_mesh) X(tri_local) X(norm) X(uv) X(albedo) X(triShadeF) X(texels) X(tex_off) X(tex_rows) X(tex_cols) X(lights) X(lightsF)
+    X(tri_mesh) X(tri_local) X(norm) X(uv) X(albedo) X(triShadeF) X(texels) X(tex_off) X(tex_rows) X(tex_cols) X(lights) X(lightsF) \
+    X(meshAlbF) X(texF) X(texels4)
 
 enum { PT_LIMIT_F32_STACK = 1, PT_LIMIT_F32_STEPS = 2, PT_LIMIT_F64_STACK = 4 };
 // ray counters of a view, the work counters the persistent primary / mirror / shading kernels draw their blocks from, the limit

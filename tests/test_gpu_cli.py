@@ -364,8 +364,11 @@ def test_nccl_backend_exchanges_on_one_rank():
     same GPU.  Two ranks cannot share a GPU under RCCL, so this is as far as a one-GPU machine goes."""
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_one_rank.py"), str(free_port())], cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=600)
+    for attempt in range(3):                # the port found free can be taken by the time the store binds it
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_one_rank.py"), str(free_port())], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=600)
+        if "EADDRINUSE" not in r.stderr:
+            break
     assert r.returncode == 0 and "nccl one-rank exchanges ok" in r.stdout, r.stdout + r.stderr
 
 
