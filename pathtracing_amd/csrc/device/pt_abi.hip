@@ -639,7 +639,7 @@ int ensure_workspace(PtScene *sc, int size, int batch, bool fast, int nsub, bool
     WS(ws_alloc(ws, P * 3 * (size_t)batch, &F.contrib));
     WS(ws_alloc(ws, P * 3, &F.rgb));
     WS(ws_alloc(ws, P * 3, &F.bgr));
-    WS(ws_alloc(ws, (size_t)RC_N, &F.counters));
+    WS(ws_alloc(ws, (size_t)RC_WORDS, &F.counters));
     WS(ws_alloc(ws, P * nsub * 3, &ws.B.paint));
     WS(ws_alloc(ws, P * nsub * 9, &ws.B.g));
     WS(ws_alloc(ws, P * nsub, &ws.B.found));
@@ -711,7 +711,7 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
     V.seed = o->seed; V.view = o->view; V.model = o->model;
     V.part = o->n_parts > 1 ? o->part : 0; V.n_parts = o->n_parts > 1 ? o->n_parts : 1;
     hipStream_t s = sc->stream;
-    HIPCHK(hipMemsetAsync(F.counters, 0, RC_N * sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync(F.counters, 0, RC_WORDS * sizeof(unsigned long long), s));
     // the kernels of a view report tripped limits in the last word of the view's counter block, read with the counters
     DevScene S = sc->S;
     S.err = F.counters + RC_LIMITS;
@@ -741,9 +741,11 @@ int render_on_device(PtScene *sc, const PtCamera *cam, const PtOptions *o, PtSta
         }
     }
     if (resolve_frame(F, size, o->gi ? 1 : 0, N, s)) return fail(PT_ERR_HIP, "resolve launch failed");
-    unsigned long long c[RC_N];
+    unsigned long long c[RC_WORDS];
     HIPCHK(hipMemcpyAsync(c, F.counters, sizeof c, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    for (unsigned h = 0; h < RC_HEAD_REGIONS; h++)                // the kernels count rays per group of blocks
+        for (unsigned k = 0; k < RC_WORK_PRIMARY; k++) c[k] += c[RC_HEADS + h * RC_HEAD_STRIDE + 1 + k];
     if (c[RC_LIMITS]) return fail(PT_ERR_LIMIT, limit_message("render", c[RC_LIMITS]));
     if (st) {
         float pms = 0;

@@ -27,11 +27,15 @@ PT_DEV uint32_t wave_sum(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// The word a block adds its count of ray class k to: one set of class words per group of blocks (see RC_HEADS), summed by the host.
+PT_DEV unsigned long long *count_word(unsigned long long *counters, int k) {
+    return counters + RC_HEADS + (blockIdx.x & (RC_HEAD_REGIONS - 1u)) * RC_HEAD_STRIDE + 1u + (unsigned)k;
+}
 PT_DEV void flush_counts(const RayCounts &rc, unsigned long long *counters) {
 #pragma unroll
     for (int k = 0; k < RC_WORK_PRIMARY; k++) {          // the ray classes; the words after them are not ray counts
         uint32_t s = wave_sum(rc.n[k]);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&counters[k], (unsigned long long)s);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(count_word(counters, k), (unsigned long long)s);
     }
 }
 
@@ -99,13 +103,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_
     uint32_t nprimary = 0;
     PktClk C;
     C.reset();
-    // persistent waves: a launched block (it owns a region of the stack overflow buffer) draws work blocks from a counter
+    // persistent waves: a launched block (it owns a region of the stack overflow buffer) draws packets from a counter:
+    // from the counter of the image band of its group first (blockIdx % 8: the blocks of a group share an XCD and its L2, and
+    // with it the band's part of the packet test's table), then from the other bands' until every band is drained
+    uint32_t tries = 0;
     for (;;) {
         const PrimaryArgsU a0 = primary_args();
+        const uint32_t nblocks = a0->nblocks, band = (nblocks + RC_HEAD_REGIONS - 1u) / RC_HEAD_REGIONS;
         uint32_t blk = 0;
-        if (lane == 0) blk = (uint32_t)atomicAdd(&a0->F.counters[RC_WORK_PRIMARY], 1ull);
-        blk = __builtin_amdgcn_readfirstlane(blk);
-        if (blk >= a0->nblocks) break;
+        while (tries < RC_HEAD_REGIONS) {
+            const uint32_t h = (blockIdx.x + tries) & (RC_HEAD_REGIONS - 1u);
+            const uint32_t lo = h * band < nblocks ? h * band : nblocks, hi = lo + band < nblocks ? lo + band : nblocks;
+            uint32_t at = 0;
+            if (lane == 0 && lo < hi) at = (uint32_t)atomicAdd(&a0->F.counters[RC_HEADS + h * RC_HEAD_STRIDE], 1ull);
+            at = __builtin_amdgcn_readfirstlane(at);
+            if (lo < hi && at < hi - lo) { blk = lo + at; break; }
+            tries++;
+        }
+        if (tries == RC_HEAD_REGIONS) break;
         int i = 0, j = 0, sub = 4;
         bool live;
         RayD ray;
@@ -142,10 +157,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_
         tuv[0] = ok ? h.tmin : -1.0; tuv[1] = h.u; tuv[2] = h.v;
         a1->B.again[slot] = again ? 1 : 0;
         C.lap(5);
+        C.packet_done();
     }
     C.flush();
     const uint32_t total = wave_sum(nprimary);
-    if (lane == 0 && total) atomicAdd(&primary_args()->F.counters[RC_PRIMARY], (unsigned long long)total);
+    // (into the word of its group: 4 096 waves ending on one word would queue up for 45 microseconds)
+    if (lane == 0 && total) atomicAdd(count_word(primary_args()->F.counters, RC_PRIMARY), (unsigned long long)total);
 }
 
 // castRay at depth 0 after its search (main.cpp:44-78 / mainOMP.cpp:40-78) up to its mirror bounce, for the sub-ray in
@@ -250,7 +267,7 @@ __global__ void __launch_bounds__(256) k_primary_shade_omp(DevScene S, ViewParam
         if ((threadIdx.x & 63) == 0 && w) atomicAdd(&sums[k], w);
     }
     __syncthreads();
-    if (threadIdx.x < RC_WORK_PRIMARY && sums[threadIdx.x]) atomicAdd(&F.counters[threadIdx.x], (unsigned long long)sums[threadIdx.x]);
+    if (threadIdx.x < RC_WORK_PRIMARY && sums[threadIdx.x]) atomicAdd(count_word(F.counters, (int)threadIdx.x), (unsigned long long)sums[threadIdx.x]);
 }
 __global__ void __launch_bounds__(64) k_primary_again(DevScene S, ViewParams V, FrameBuffers F, SubBuffers B) {
     extern __shared__ double stack_lds[];
@@ -488,7 +505,7 @@ int exact_primary(const DevScene &S, const ViewParams &V, const FrameBuffers &F,
             unsigned long long c[16];
             if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(c, HIP_SYMBOL(g_pkt_clk), sizeof c) == hipSuccess) {
                 fprintf(stderr, "pkt_clk");
-                for (int k = 0; k < 6; k++) fprintf(stderr, " %llu/%llu", c[k], c[8 + k]);
+                for (int k = 0; k < 8; k++) fprintf(stderr, " %llu/%llu", c[k], c[8 + k]);
                 fprintf(stderr, "\n");
                 for (int k = 0; k < 16; k++) c[k] = 0;
                 (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pkt_clk), c, sizeof c);

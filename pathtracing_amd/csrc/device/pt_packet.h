@@ -27,20 +27,23 @@
 
 // PT_PKT_CLOCKS (an instrumented build for tools/pkt_clocks.sh, never the product): wave clocks per part of the walk.
 // Slots: 0 pop, 1 node fetch, 2 packet test of a list, 3 triangle fetch + the reference's test, 4 the step to the
-// children, 5 everything else of a packet (set-up, results).
+// children, 5 everything else of a packet (set-up, results), 6 the first packet test of a packet (counted apart from 2),
+// 7 the whole first packet of a wave (also counted in the other slots).
 #ifdef PT_PKT_CLOCKS
 __device__ unsigned long long g_pkt_clk[16];
 struct PktClk {
-    unsigned long long acc[6], cnt[6], t;
-    PT_DEV void reset() { for (int k = 0; k < 6; k++) acc[k] = cnt[k] = 0; t = __builtin_amdgcn_s_memtime(); }
+    unsigned long long acc[8], cnt[8], t, t_wave; bool first;
+    PT_DEV void reset() { for (int k = 0; k < 8; k++) acc[k] = cnt[k] = 0; t = t_wave = __builtin_amdgcn_s_memtime(); first = true; }
+    PT_DEV void packet_done() { if (cnt[7] == 0) { acc[7] = __builtin_amdgcn_s_memtime() - t_wave; cnt[7] = 1; } }
     PT_DEV void lap(int slot) { const unsigned long long n = __builtin_amdgcn_s_memtime(); acc[slot] += n - t; cnt[slot]++; t = n; }
+    PT_DEV void lap2() { lap(first ? 6 : 2); first = false; }
     PT_DEV void flush() {
         if ((threadIdx.x & 63u) == 0)
-            for (int k = 0; k < 6; k++) { atomicAdd(&g_pkt_clk[k], acc[k]); atomicAdd(&g_pkt_clk[8 + k], cnt[k]); }
+            for (int k = 0; k < 8; k++) { atomicAdd(&g_pkt_clk[k], acc[k]); atomicAdd(&g_pkt_clk[8 + k], cnt[k]); }
     }
 };
 #else
-struct PktClk { PT_DEV void reset() {} PT_DEV void lap(int) {} PT_DEV void flush() {} };
+struct PktClk { bool first; PT_DEV void reset() {} PT_DEV void lap(int) {} PT_DEV void lap2() {} PT_DEV void packet_done() {} PT_DEV void flush() {} };
 #endif
 
 PT_DEV double wave_min_d(double v) {
@@ -251,7 +254,7 @@ PT_DEV bool packet_node(const DevScene &S, int node0, int first0, int count0, co
             }
             surv = __ballot(keep);
         }
-        C.lap(2);
+        C.lap2();
         if (!surv) continue;
         // the triangles that are left, one after the other for the whole wave; the next one is on its way while this one is tested
         int k = first0 + base + (int)__builtin_ctzll(surv);
@@ -319,6 +322,7 @@ PT_DEV bool packet_search(const DevScene &S, const RayD &ray_in, bool live, cons
     unsigned long long act = __ballot(in);
     int curr = 0;
     C.lap(5);
+    C.first = true;
     // One loop with one back edge: a turn pops an entry if no ray is in the current node, and then, if some ray is in
     // the (new) current node, does that node.
     for (;;) {
