@@ -204,17 +204,21 @@ __device__ __forceinline__ uint32_t dir_bin(float x, float y, float z) {
 }
 static_assert(PT_GEN_CELL_BITS <= 8, "the bit interleave of dir_bin handles 8 bits per coordinate");
 
-// T threads per block (1 024 or 512): a block takes one tile of 64 pixels and 4 * T / 64 samples of each -- four per thread.
-template <int T>
-__global__ void __launch_bounds__(T) k_gi_gen(DevScene S, ViewParams V, FrameBuffers F, FastBuffers Q, int s0, int nb, int groups) {
-    constexpr int WAVES = T / 64, SPB = 4 * WAVES, RAYS = 64 * SPB;      // samples per pixel and rays of a block
+// T threads per block (1 024 or 512), G tiles per block (1 or 4): a block takes G neighbouring tiles of 64 pixels (in queue
+// order) and 4 * T / (64 G) samples of each -- four rays per thread -- and sorts them as one run.  G = 4 is for passes of at most
+// 16 samples (the reference's defaults): the run is as long as with 64 samples of one tile, so the closest-hit kernel
+// meets rays as well sorted by direction as at high sample counts, and every thread of the block has rays to make.
+template <int T, int G>
+__global__ void __launch_bounds__(T) k_gi_gen(DevScene S, ViewParams V, FrameBuffers F, FastBuffers Q, int s0, int nb, int groups, int tiles) {
+    constexpr int WAVES = T / 64, SPB = 4 * WAVES / G, PX = 64 * G, RAYS = PX * SPB;      // samples per pixel, pixels and rays of a block
+    static_assert(WAVES % G == 0, "waves of a block per tile");
     __shared__ uint32_t hist[PT_GEN_BINS];                   // rays per direction cell, then (in place) the cell's first place in the block's run
     __shared__ uint32_t block_base, wave_sum[WAVES];
-    const int tid = threadIdx.x;
-    const int qtile = blockIdx.x / groups, group = blockIdx.x - qtile * groups;
-    const int tile = ordered_tile(qtile, V.size);
-    int i, j;
-    const bool live = tile_pixel_f(tile * 64 + (tid & 63), V.size, i, j);
+    const int tid = threadIdx.x, wv = tid >> 6;
+    const int qgroup = blockIdx.x / groups, group = blockIdx.x - qgroup * groups;
+    const int qtile = qgroup * G + wv % G, ssub = wv / G;    // this thread's tile and its place among the samples of a round
+    int i = 0, j = 0;
+    const bool live = qtile < tiles && tile_pixel_f(ordered_tile(qtile, V.size) * 64 + (tid & 63), V.size, i, j);
     const size_t p = live ? (size_t)i * V.size + j : 0;
     for (int k = tid; k < PT_GEN_BINS; k += T) hist[k] = 0;
     __syncthreads();
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(T) k_gi_gen(DevScene S, ViewParams V, FrameBuf
     uint32_t key[4], rank[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int sl = group * SPB + r * WAVES + (tid >> 6);
+        const int sl = group * SPB + r * (WAVES / G) + ssub;
         key[r] = 0xFFFFFFFFu;
         if (live && sl < nb) {
             if (pix_valid) {
@@ -288,10 +292,11 @@ __global__ void __launch_bounds__(T) k_gi_gen(DevScene S, ViewParams V, FrameBuf
             if (first + k < PT_GEN_BINS) { hist[first + k] = run; run += mine[k]; }
         // the block's place in the queue is fixed: tiles in queue order, the sample groups of a tile one after another
         if (tid == 0) {
-            const uint32_t t0 = Q.tile_base[qtile], valid = Q.tile_base[qtile + 1] - t0;
+            const int q0 = qgroup * G, q1 = q0 + G < tiles ? q0 + G : tiles;
+            const uint32_t t0 = Q.tile_base[q0], valid = Q.tile_base[q1] - t0;
             const uint32_t done_samples = (uint32_t)(group * SPB < nb ? group * SPB : nb);
             block_base = t0 * (uint32_t)nb + valid * done_samples;
-            if (blockIdx.x == 0) Q.counts[0] = Q.tile_base[gridDim.x / groups] * (uint32_t)nb;
+            if (blockIdx.x == 0) Q.counts[0] = Q.tile_base[tiles] * (uint32_t)nb;
         }
         in_block = total;
     }
@@ -299,29 +304,29 @@ __global__ void __launch_bounds__(T) k_gi_gen(DevScene S, ViewParams V, FrameBuf
     // The sorted order is made in LDS -- every ray's direction and code dropped at its place in the block's run -- and the
     // run then leaves for the queue in whole lines: written straight from the threads, 16 bytes each at a random place
     // of the run, the three arrays cost 0.3 ms more per 67 M rays.  The origin is the pixel's, found through the code.
-    extern __shared__ float4 staged[];                       // RAYS directions, 64 origins, RAYS codes
+    extern __shared__ float4 staged[];                       // RAYS directions, PX origins, RAYS codes
     float4 *stage_d = staged, *stage_o = staged + RAYS;
-    uint32_t *stage_c = (uint32_t *)(staged + RAYS + 64);
-    if (tid < 64) stage_o[tid] = ro;
+    uint32_t *stage_c = (uint32_t *)(staged + RAYS + PX);
+    if (tid < PX) stage_o[tid] = ro;                         // (the first G waves: ssub == 0, one thread per pixel of the block)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         if (key[r] != 0xFFFFFFFFu) {
-            const int sl = group * SPB + r * WAVES + (tid >> 6);
+            const int sl = group * SPB + r * (WAVES / G) + ssub;
             const uint32_t at = hist[key[r]] + rank[r];
             stage_d[at] = rd[r];
-            stage_c[at] = (uint32_t)sl * 64u + (uint32_t)(tid & 63);
+            stage_c[at] = (uint32_t)sl * (uint32_t)PX + (uint32_t)(tid & (PX - 1));
             if (__float_as_uint(rd[r].w) >> 31) Q.hits[block_base + at] = make_float4(st[r], su[r], sv[r], __int_as_float(otri));
         }
     }
     __syncthreads();
     for (uint32_t k = tid; k < in_block; k += T) {
         const uint32_t code = stage_c[k], q = block_base + k;
-        Q.rays_o[q] = stage_o[code & 63u];
+        Q.rays_o[q] = stage_o[code & (uint32_t)(PX - 1)];
         Q.rays_d[q] = stage_d[k];
         Q.ray_slot[q] = code;
     }
 }
-#define PT_GEN_LDS_BYTES(T) ((size_t)((T) * 4 + 64) * sizeof(float4) + (size_t)(T) * 4 * sizeof(uint32_t))
+#define PT_GEN_LDS_BYTES(T, G) ((size_t)((T) * 4 + 64 * (G)) * sizeof(float4) + (size_t)(T) * 4 * sizeof(uint32_t))
 
 // ---- stage 2: closest hit -------------------------------------------------------
 // LS: LaneState (binary node records, pt_trace_f32.h) or LaneStateQ (quad records, pt_trace_quad.h); the same search.
@@ -612,34 +617,37 @@ __global__ void __launch_bounds__(256) k_light_sum(DevScene S, FastBuffers Q) {
 // drops every entry into LDS at the place its code names -- the scatter that sorting the rays made necessary happens
 // in LDS, not in device memory, where 16-byte writes at random places cost the shading kernel 0.7 ms per 67 M rays --
 // and then every pixel adds its samples in sample order in fp64, as the reference's loop does (main.cpp:129-133).
+// G: the tiles a block of the generator sorted as one run (1 or 4); the block then takes those G tiles, 64 / G samples at a time.
 #define PT_SUM_THREADS 256
-__global__ void __launch_bounds__(PT_SUM_THREADS) k_gi_sum(FrameBuffers F, FastBuffers Q, int size, int nb, int first_batch) {
+template <int G>
+__global__ void __launch_bounds__(PT_SUM_THREADS) k_gi_sum(FrameBuffers F, FastBuffers Q, int size, int nb, int first_batch, int tiles) {
+    constexpr int PX = 64 * G, CH = 64 / G;
     __shared__ float cr[64 * 64], cg[64 * 64], cb[64 * 64];
-    const int tid = threadIdx.x, qtile = blockIdx.x;
-    if (qtile == 0 && tid == 0) {                   // the pass's ray counts join the totals of the view (read once, at its end)
+    const int tid = threadIdx.x, qgroup = blockIdx.x;
+    if (qgroup == 0 && tid == 0) {                  // the pass's ray counts join the totals of the view (read once, at its end)
         Q.totals[0] += Q.counts[0];
         Q.totals[1] += Q.counts[2];
     }
-    const int tile = ordered_tile(qtile, size);
-    const uint32_t t0 = Q.tile_base[qtile], valid = Q.tile_base[qtile + 1] - t0;
-    int i, j;
-    const bool mine = tid < 64 && tile_pixel_f(tile * 64 + tid, size, i, j);
+    const int q0 = qgroup * G, q1 = q0 + G < tiles ? q0 + G : tiles, qtile = q0 + (tid >> 6);
+    const uint32_t t0 = Q.tile_base[q0], valid = Q.tile_base[q1] - t0;
+    int i = 0, j = 0;
+    const bool mine = tid < PX && qtile < tiles && tile_pixel_f(ordered_tile(qtile, size) * 64 + (tid & 63), size, i, j);
     const size_t p = mine ? (size_t)i * size + j : 0;
     double ax = 0, ay = 0, az = 0;
     if (mine && !first_batch) { ax = F.gi_acc[3 * p]; ay = F.gi_acc[3 * p + 1]; az = F.gi_acc[3 * p + 2]; }
     // a pixel without a primary hit shot no rays (main.cpp:86 returns 0 for it)
     const bool shot = mine && !(F.ghit[3 * p] == -99999);
-    for (int g0 = 0; g0 < nb && valid; g0 += 64) {
-        const int gs = nb - g0 < 64 ? nb - g0 : 64;
+    for (int g0 = 0; g0 < nb && valid; g0 += CH) {
+        const int gs = nb - g0 < CH ? nb - g0 : CH;
         const uint32_t base = t0 * (uint32_t)nb + valid * (uint32_t)g0, n = valid * (uint32_t)gs;
         for (uint32_t k = tid; k < n; k += PT_SUM_THREADS) {
             const float4 c = Q.contrib[base + k];
-            const uint32_t at = Q.ray_slot[base + k] - (uint32_t)g0 * 64u;
+            const uint32_t at = Q.ray_slot[base + k] - (uint32_t)g0 * (uint32_t)PX;
             cr[at] = c.x; cg[at] = c.y; cb[at] = c.z;
         }
         __syncthreads();
         if (shot)
-            for (int s = 0; s < gs; s++) { ax += (double)cr[s * 64 + tid]; ay += (double)cg[s * 64 + tid]; az += (double)cb[s * 64 + tid]; }
+            for (int s = 0; s < gs; s++) { ax += (double)cr[s * PX + tid]; ay += (double)cg[s * PX + tid]; az += (double)cb[s * PX + tid]; }
         __syncthreads();
     }
     if (mine) { F.gi_acc[3 * p] = ax; F.gi_acc[3 * p + 1] = ay; F.gi_acc[3 * p + 2] = az; }
@@ -649,18 +657,20 @@ __global__ void __launch_bounds__(PT_SUM_THREADS) k_gi_sum(FrameBuffers F, FastB
 // shades the tile's rays itself and drops the results straight into LDS, so the contributions never travel to device
 // memory and back (32 bytes per ray) and one launch per pass goes.
 #define PT_FUSED_THREADS 1024
-__global__ void __launch_bounds__(PT_FUSED_THREADS) k_shade_sum_omp(DevScene S, FrameBuffers F, FastBuffers Q, int size, int nb, int first_batch) {
+template <int G>
+__global__ void __launch_bounds__(PT_FUSED_THREADS) k_shade_sum_omp(DevScene S, FrameBuffers F, FastBuffers Q, int size, int nb, int first_batch, int tiles) {
+    constexpr int PX = 64 * G, CH = 64 / G;
     __shared__ float cr[64 * 64], cg[64 * 64], cb[64 * 64];
-    __shared__ float org[3][64];                    // the rays' origins: the primary hits of the tile's pixels, as k_gi_gen rounds them
-    const int tid = threadIdx.x, qtile = blockIdx.x;
-    if (qtile == 0 && tid == 0) {
+    __shared__ float org[3][PX];                    // the rays' origins: the primary hits of the block's pixels, as k_gi_gen rounds them
+    const int tid = threadIdx.x, qgroup = blockIdx.x;
+    if (qgroup == 0 && tid == 0) {
         Q.totals[0] += Q.counts[0];
         Q.totals[1] += Q.counts[2];
     }
-    const int tile = ordered_tile(qtile, size);
-    const uint32_t t0 = Q.tile_base[qtile], valid = Q.tile_base[qtile + 1] - t0;
-    int i, j;
-    const bool mine = tid < 64 && tile_pixel_f(tile * 64 + tid, size, i, j);
+    const int q0 = qgroup * G, q1 = q0 + G < tiles ? q0 + G : tiles, qtile = q0 + (tid >> 6);
+    const uint32_t t0 = Q.tile_base[q0], valid = Q.tile_base[q1] - t0;
+    int i = 0, j = 0;
+    const bool mine = tid < PX && qtile < tiles && tile_pixel_f(ordered_tile(qtile, size) * 64 + (tid & 63), size, i, j);
     const size_t p = mine ? (size_t)i * size + j : 0;
     double ax = 0, ay = 0, az = 0;
     if (mine && !first_batch) { ax = F.gi_acc[3 * p]; ay = F.gi_acc[3 * p + 1]; az = F.gi_acc[3 * p + 2]; }
@@ -671,18 +681,18 @@ __global__ void __launch_bounds__(PT_FUSED_THREADS) k_shade_sum_omp(DevScene S, 
         org[0][tid] = (float)hx; org[1][tid] = (float)hy; org[2][tid] = (float)hz;
     }
     __syncthreads();
-    for (int g0 = 0; g0 < nb && valid; g0 += 64) {
-        const int gs = nb - g0 < 64 ? nb - g0 : 64;
+    for (int g0 = 0; g0 < nb && valid; g0 += CH) {
+        const int gs = nb - g0 < CH ? nb - g0 : CH;
         const uint32_t base = t0 * (uint32_t)nb + valid * (uint32_t)g0, n = valid * (uint32_t)gs;
         for (uint32_t k = tid; k < n; k += PT_FUSED_THREADS) {
             const uint32_t r = base + k;
-            const uint32_t code = Q.ray_slot[r], px = code & 63u, at = code - (uint32_t)g0 * 64u;
+            const uint32_t code = Q.ray_slot[r], px = code & (uint32_t)(PX - 1), at = code - (uint32_t)g0 * (uint32_t)PX;
             const float4 c = omp_contribution(S, org[0][px], org[1][px], org[2][px], Q.rays_d[r], Q.hits[r]);
             cr[at] = c.x; cg[at] = c.y; cb[at] = c.z;
         }
         __syncthreads();
         if (shot)
-            for (int s = 0; s < gs; s++) { ax += (double)cr[s * 64 + tid]; ay += (double)cg[s * 64 + tid]; az += (double)cb[s * 64 + tid]; }
+            for (int s = 0; s < gs; s++) { ax += (double)cr[s * PX + tid]; ay += (double)cg[s * PX + tid]; az += (double)cb[s * PX + tid]; }
         __syncthreads();
     }
     if (mine) { F.gi_acc[3 * p] = ax; F.gi_acc[3 * p + 1] = ay; F.gi_acc[3 * p + 2] = az; }
@@ -763,10 +773,13 @@ int fast_alloc(FastBuffers Q[2], size_t pixels, int batch, int n_light, PtAllocF
 // Launch parameters of the closest-hit kernel.  The defaults are what the
 // measurements in profiles/ were taken with; the PT_TUNE_* environment
 // variables exist for sweeps.
-struct TraceTune { int slots, refill, waves, chunk, gen_lds, shade_lds, gen_threads; };
+struct TraceTune { int slots, refill, waves, chunk, gen_lds, shade_lds, gen_threads, sort_tiles; };
+// Tiles the generator sorts as one run in a pass of nb samples per pixel: 4 when the pass is short (see k_gi_gen).
+static int sort_tiles(int nb, const TraceTune &t) { return nb <= 16 ? t.sort_tiles : 1; }
 static TraceTune trace_tune() {
     TraceTune t = [] {
-        TraceTune v{FS_SLOTS, PT_REFILL_MIN, PT_TRACE_WAVES, PT_QUEUE_CHUNK, 0, PT_SHADE_LDS_BYTES, PT_GEN_THREADS};
+        TraceTune v{FS_SLOTS, PT_REFILL_MIN, PT_TRACE_WAVES, PT_QUEUE_CHUNK, 0, PT_SHADE_LDS_BYTES, PT_GEN_THREADS, 4};
+        if (const char *e = getenv("PT_TUNE_SORT_TILES")) { int k = atoi(e); if (k == 1 || k == 4) v.sort_tiles = k; }
         if (const char *e = getenv("PT_TUNE_GEN_THREADS")) { int k = atoi(e); if (k == 512 || k == 1024) v.gen_threads = k; }
         if (const char *e = getenv("PT_TUNE_GEN_LDS")) { int k = atoi(e); if (k >= 0 && k <= 150000) v.gen_lds = k; }
         if (const char *e = getenv("PT_TUNE_SHADE_LDS")) { int k = atoi(e); if (k >= 0 && k <= 150000) v.shade_lds = k; }
@@ -803,32 +816,32 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
     const FastBuffers &Q0 = QQ[0];
     if (work) FQ(hipMemsetAsync(Q0.work, 0, 2 * sizeof(unsigned long long), s));
     FQ(hipMemsetAsync(Q0.totals, 0, 2 * sizeof(unsigned long long), s));
-    {
-        const int tiles = tthreads / 64;
-        hipLaunchKernelGGL(k_tile_valid, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, s, F, Q0, V.size, tiles);
-        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, Q0, tiles);
-    }
+    const int tiles = tthreads / 64;
+    hipLaunchKernelGGL(k_tile_valid, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, s, F, Q0, V.size, tiles);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, Q0, tiles);
     hipEvent_t view_ready = events[4 * (size_t)npass];             // G-buffer and tile offsets are in place
     FQ(hipEventRecord(view_ready, s));
     auto generate = [&](int pass) -> int {
         const FastBuffers &Q = QQ[pass & 1];
-        const int s0 = pass * batch, nb = nsamples - s0 < batch ? nsamples - s0 : batch, spb = tune.gen_threads / 16, groups = (nb + spb - 1) / spb;
+        const int s0 = pass * batch, nb = nsamples - s0 < batch ? nsamples - s0 : batch;
+        const int G = sort_tiles(nb, tune), spb = tune.gen_threads / (16 * G), groups = (nb + spb - 1) / spb;
+        const unsigned blocks = (unsigned)(((tiles + G - 1) / G) * groups);
         // the ray set is free once the pass before the previous one is done (pass 0 and 1: once the view is ready);
         // the generator then runs beside the start of the previous pass's traversal.  (Holding it back until that
         // traversal has ended, so that it runs beside the shading instead, was slower.)
         FQ(hipStreamWaitEvent(s_gen, pass >= 2 ? events[4 * (pass - 2) + 3] : view_ready, 0));
         FQ(hipMemsetAsync(Q.counts, 0, (PT_PASS_COUNT_WORDS + 2 * PT_HEAD_WORDS) * sizeof(uint32_t), s_gen));
-        if (tune.gen_threads == 512)
-            hipLaunchKernelGGL(k_gi_gen<512>, dim3((unsigned)((tthreads / 64) * groups)), dim3(512), PT_GEN_LDS_BYTES(512) + (size_t)tune.gen_lds, s_gen, S, V, F, Q, s0, nb, groups);
-        else
-            hipLaunchKernelGGL(k_gi_gen<1024>, dim3((unsigned)((tthreads / 64) * groups)), dim3(1024), PT_GEN_LDS_BYTES(1024) + (size_t)tune.gen_lds, s_gen, S, V, F, Q, s0, nb, groups);
+#define PT_GEN_LAUNCH(T, G) hipLaunchKernelGGL((k_gi_gen<T, G>), dim3(blocks), dim3(T), PT_GEN_LDS_BYTES(T, G) + (size_t)tune.gen_lds, s_gen, S, V, F, Q, s0, nb, groups, tiles)
+        if (tune.gen_threads == 512) { if (G == 4) PT_GEN_LAUNCH(512, 4); else PT_GEN_LAUNCH(512, 1); }
+        else { if (G == 4) PT_GEN_LAUNCH(1024, 4); else PT_GEN_LAUNCH(1024, 1); }
+#undef PT_GEN_LAUNCH
         FQ(hipEventRecord(events[4 * pass], s_gen));
         return PT_OK;
     };
     if (int rc = generate(0)) return rc;
     for (int pass = 0; pass < npass; pass++) {
         const FastBuffers &Q = QQ[pass & 1];
-        const int s0 = pass * batch, nb = nsamples - s0 < batch ? nsamples - s0 : batch;
+        const int s0 = pass * batch, nb = nsamples - s0 < batch ? nsamples - s0 : batch, G = sort_tiles(nb, tune);
         if ((size_t)nb * P > Q.max_rays) return PT_ERR_LIMIT;
         if (V.model == PT_MODEL_MAIN && !Q.sh_o) return PT_ERR_LIMIT;     // the shadow-ray queue was not asked for
         if (pass + 1 < npass)
@@ -862,14 +875,16 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         } else {
             static const bool fused = !(getenv("PT_TUNE_FUSED_SUM") && atoi(getenv("PT_TUNE_FUSED_SUM")) == 0);
             if (fused) {
-                hipLaunchKernelGGL(k_shade_sum_omp, dim3((unsigned)(tthreads / 64)), dim3(PT_FUSED_THREADS), 0, s, S, F, Q, V.size, nb, s0 == 0);
+                if (G == 4) hipLaunchKernelGGL(k_shade_sum_omp<4>, dim3((unsigned)((tiles + 3) / 4)), dim3(PT_FUSED_THREADS), 0, s, S, F, Q, V.size, nb, s0 == 0, tiles);
+                else hipLaunchKernelGGL(k_shade_sum_omp<1>, dim3((unsigned)tiles), dim3(PT_FUSED_THREADS), 0, s, S, F, Q, V.size, nb, s0 == 0, tiles);
                 FQ(hipEventRecord(events[4 * pass + 3], s));
                 FQ(hipGetLastError());
                 continue;
             }
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_OMP>, dim3(sblocks), dim3(PT_APPEND_BLOCK), (size_t)tune.shade_lds, s, S, Q);
         }
-        hipLaunchKernelGGL(k_gi_sum, dim3((unsigned)(tthreads / 64)), dim3(PT_SUM_THREADS), 0, s, F, Q, V.size, nb, s0 == 0);
+        if (G == 4) hipLaunchKernelGGL(k_gi_sum<4>, dim3((unsigned)((tiles + 3) / 4)), dim3(PT_SUM_THREADS), 0, s, F, Q, V.size, nb, s0 == 0, tiles);
+        else hipLaunchKernelGGL(k_gi_sum<1>, dim3((unsigned)tiles), dim3(PT_SUM_THREADS), 0, s, F, Q, V.size, nb, s0 == 0, tiles);
         FQ(hipEventRecord(events[4 * pass + 3], s));
         FQ(hipGetLastError());
     }

@@ -133,18 +133,21 @@ def test_rm_job_frames_do_not_depend_on_the_number_of_ranks(tmp_path, cbox):
         assert np.array_equal(a, want), v
 
 
-@pytest.mark.parametrize("scene,model", [("car", "omp"), ("cbox", "main")])
-def test_kernel_variants_write_the_same_frame(tmp_path, scene, model):
+@pytest.mark.parametrize("scene,model,spp,size", [("car", "omp", 70, 96), ("cbox", "main", 70, 96), ("car", "omp", 16, 100), ("cbox", "main", 4, 100)])
+def test_kernel_variants_write_the_same_frame(tmp_path, scene, model, spp, size):
     """The fp32 GI path has two forms of its tree walk (quad records, two levels per record, and the binary records kept
-    for the no-allocation entry point) and, for the mainOMP model, shading and summing as one kernel or as two.  They are
-    the same computation: a -gi frame is the same bytes whichever is chosen (the switches are read once per process,
-    hence one process per variant)."""
+    for the no-allocation entry point) and, for the mainOMP model, shading and summing as one kernel or as two; the ray
+    generator sorts the rays of one tile or, in passes of at most 16 samples, of four tiles as one run, in blocks of 1 024 or
+    512 threads (size 100: 169 tiles, so the last group of four is not full).  They are the same computation: a -gi frame
+    is the same bytes whichever is chosen (the switches are read once per process, hence one process per variant)."""
     frames = {}
     for name, env in (("default", {}), ("binary records", {"PT_TUNE_QUAD": "0"}), ("two kernels", {"PT_TUNE_FUSED_SUM": "0"}),
-                      ("both", {"PT_TUNE_QUAD": "0", "PT_TUNE_FUSED_SUM": "0"})):
-        out = tmp_path / name.replace(" ", "_")
+                      ("both", {"PT_TUNE_QUAD": "0", "PT_TUNE_FUSED_SUM": "0"}), ("one tile per run", {"PT_TUNE_SORT_TILES": "1"}),
+                      ("small generator blocks", {"PT_TUNE_GEN_THREADS": "512"}),
+                      ("one tile, small blocks, two kernels", {"PT_TUNE_SORT_TILES": "1", "PT_TUNE_GEN_THREADS": "512", "PT_TUNE_FUSED_SUM": "0"})):
+        out = tmp_path / name.replace(" ", "_").replace(",", "")
         os.makedirs(out)
-        r = subprocess.run([PTMAIN, scene, "-gi", "--model", model, "--spp", "70", "--size", "96", "--out", str(out)], cwd=ROOT,
+        r = subprocess.run([PTMAIN, scene, "-gi", "--model", model, "--spp", str(spp), "--size", str(size), "--out", str(out)], cwd=ROOT,
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         frames[name] = read_ppm(out / f"{scene}.ppm")
