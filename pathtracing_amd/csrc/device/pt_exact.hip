@@ -112,6 +112,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_
         const uint32_t nblocks = a0->nblocks, band = (nblocks + RC_HEAD_REGIONS - 1u) / RC_HEAD_REGIONS;
         uint32_t blk = 0;
         while (tries < RC_HEAD_REGIONS) {
+            if (tries) {                             // has a wave of this group already found every band drained?
+                unsigned long long seen = 0;
+                if (lane == 0) seen = __hip_atomic_fetch_add((unsigned long long *)&a0->F.counters[RC_FLAGS + (blockIdx.x & (RC_HEAD_REGIONS - 1u)) * RC_HEAD_STRIDE], 2ull,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane((uint32_t)seen) & 1u) { tries = RC_HEAD_REGIONS; break; }
+            }
             const uint32_t h = (blockIdx.x + tries) & (RC_HEAD_REGIONS - 1u);
             const uint32_t lo = h * band < nblocks ? h * band : nblocks, hi = lo + band < nblocks ? lo + band : nblocks;
             uint32_t at = 0;
@@ -120,7 +126,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_
             if (lo < hi && at < hi - lo) { blk = lo + at; break; }
             tries++;
         }
-        if (tries == RC_HEAD_REGIONS) break;
+        if (tries == RC_HEAD_REGIONS) {
+            if (lane == 0) atomicOr((unsigned long long *)&a0->F.counters[RC_FLAGS + (blockIdx.x & (RC_HEAD_REGIONS - 1u)) * RC_HEAD_STRIDE], 1ull);
+            break;
+        }
         int i = 0, j = 0, sub = 4;
         bool live;
         RayD ray;

@@ -32,6 +32,22 @@
 #define PT_HEAD_STRIDE 64u                    // words between region heads
 #define PT_HEAD_WORDS (PT_QUEUE_REGIONS * PT_HEAD_STRIDE)
 
+// The end of a launch: every wave has to find every region drained, and 8 192 waves each adding to each of the eight
+// head words queue up for 90 us per word.  The first wave of a group that has seen all eight drained therefore says so in a
+// word of its group, and the other waves of the group look there before they try another region: two or three updates
+// per wave at the end instead of eight.  The word only ever says what is true for good (heads only grow); a wave that
+// looks too early checks the regions itself, as before.
+__device__ __forceinline__ bool group_done(uint32_t *heads, uint32_t home) {
+    uint32_t v = 0;
+    // (an update that changes the word -- it counts the lookers in the bits above the flag -- so that it is not turned into a
+    // load that a cache may answer with an old value)
+    if ((threadIdx.x & 63) == 0) v = __hip_atomic_fetch_add(heads + home * PT_HEAD_STRIDE + PT_HEAD_STRIDE / 2, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (__builtin_amdgcn_readfirstlane(v) & 1u) != 0u;
+}
+__device__ __forceinline__ void group_is_done(uint32_t *heads, uint32_t home) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(heads + home * PT_HEAD_STRIDE + PT_HEAD_STRIDE / 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <class Policy>
 __device__ __forceinline__ void persistent_loop(Policy &P, uint32_t n_items, uint32_t *heads, uint32_t chunk, int refill_min) {
     const uint32_t lane = threadIdx.x & 63;
@@ -45,6 +61,7 @@ __device__ __forceinline__ void persistent_loop(Policy &P, uint32_t n_items, uin
         if (more && __popcll(idle) >= refill_min) {
             if (chunk_next == chunk_end) {
                 while (tries < PT_QUEUE_REGIONS) {
+                    if (tries && group_done(heads, home)) { tries = PT_QUEUE_REGIONS; break; }
                     const uint32_t h = (home + tries) & (PT_QUEUE_REGIONS - 1u);
                     const uint32_t lo = h * region_len < n_items ? h * region_len : n_items;
                     const uint32_t hi = lo + region_len < n_items ? lo + region_len : n_items;
@@ -58,7 +75,7 @@ __device__ __forceinline__ void persistent_loop(Policy &P, uint32_t n_items, uin
                     }
                     tries++;
                 }
-                if (tries == PT_QUEUE_REGIONS) more = false;
+                if (tries == PT_QUEUE_REGIONS) { more = false; group_is_done(heads, home); }
             }
             const uint32_t want = (uint32_t)__popcll(idle), have = chunk_end - chunk_next;
             const uint32_t take = want < have ? want : have, base = chunk_next;
