@@ -183,9 +183,11 @@ template <int MODEL, bool SEARCH>
 PT_DEV void shade_sub_ray(const DevScene &S, const ViewParams &V, const SubBuffers &B, StackD &st, RayCounts &rc, int i, int j, int sub, size_t slot) {
     D3 paint;
     int mirror = 0;
+    // whose G-buffer candidate k_primary_combine reads: every sub-ray's for main.cpp (the last one wins), the centre ray's
+    // for mainOMP.cpp; of the others only the hit point is kept, and only where the mirror pass starts its ray from it
+    const bool g_read = MODEL == PT_MODEL_MAIN || !V.rb || sub == 4;
     if (!B.found[slot]) {
-        const D3 zero = d3(0, 0, 0);
-        dstore(B.g + 9 * slot, zero); dstore(B.g + 9 * slot + 3, zero); dstore(B.g + 9 * slot + 6, d3(-99999, -99999, -99999));
+        if (g_read) dstore(B.g + 9 * slot + 6, d3(-99999, -99999, -99999));      // (colour and normal of a miss are not read)
         paint = d3(S.bg[0], S.bg[1], S.bg[2]);
     } else {
         const RayD ray = sub_ray(V, i, j, sub);
@@ -193,7 +195,8 @@ PT_DEV void shade_sub_ray(const DevScene &S, const ViewParams &V, const SubBuffe
         c.h.tri = B.tri[slot]; c.h.tmin = B.tuv[3 * slot]; c.h.u = B.tuv[3 * slot + 1]; c.h.v = B.tuv[3 * slot + 2];
         cast_lights<MODEL, SEARCH>(S, ray, st, rc, c, MODEL == PT_MODEL_OMP && !B.again[slot]);
         // the G-buffer candidate goes to memory as soon as it is known
-        dstore(B.g + 9 * slot, dmul(c.txt, c.alb)); dstore(B.g + 9 * slot + 3, c.nrm); dstore(B.g + 9 * slot + 6, c.hit);
+        if (g_read) { dstore(B.g + 9 * slot, dmul(c.txt, c.alb)); dstore(B.g + 9 * slot + 3, c.nrm); }
+        if (g_read || c.reft) dstore(B.g + 9 * slot + 6, c.hit);
         if (MODEL == PT_MODEL_OMP && SEARCH) {       // a second search that did find something closer moved the record (mainOMP.cpp:60)
             B.tri[slot] = c.h.tri;
             B.tuv[3 * slot] = c.h.tmin; B.tuv[3 * slot + 1] = c.h.u; B.tuv[3 * slot + 2] = c.h.v;

@@ -144,16 +144,13 @@ __device__ __forceinline__ int ordered_tile(int q, int size) {
 }
 
 // Pixels with a primary hit per tile, in queue order (once per view) ...
-__global__ void k_tile_valid(FrameBuffers F, FastBuffers Q, int size, int tiles) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_tile_valid(FrameBuffers F, FastBuffers Q, int size, int tiles) {
+    const int q = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);          // a wave per tile, a lane per pixel
     if (q >= tiles) return;
-    const int tile = ordered_tile(q, size);
-    uint32_t n = 0;
-    for (int l = 0; l < 64; l++) {
-        int i, j;
-        if (tile_pixel_f(tile * 64 + l, size, i, j)) n += !(F.ghit[3 * ((size_t)i * size + j)] == -99999);
-    }
-    Q.tile_base[q] = n;
+    int i, j;
+    const bool hit = tile_pixel_f(ordered_tile(q, size) * 64 + (int)(threadIdx.x & 63), size, i, j) && !(F.ghit[3 * ((size_t)i * size + j)] == -99999);
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0) Q.tile_base[q] = (uint32_t)__popcll(m);
 }
 // ... and their exclusive prefix sum in place, total in tile_base[tiles]: where each tile's rays start in the queue.
 __global__ void __launch_bounds__(1024) k_tile_scan(FastBuffers Q, int tiles) {
@@ -817,7 +814,7 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
     if (work) FQ(hipMemsetAsync(Q0.work, 0, 2 * sizeof(unsigned long long), s));
     FQ(hipMemsetAsync(Q0.totals, 0, 2 * sizeof(unsigned long long), s));
     const int tiles = tthreads / 64;
-    hipLaunchKernelGGL(k_tile_valid, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, s, F, Q0, V.size, tiles);
+    hipLaunchKernelGGL(k_tile_valid, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, F, Q0, V.size, tiles);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, Q0, tiles);
     hipEvent_t view_ready = events[4 * (size_t)npass];             // G-buffer and tile offsets are in place
     FQ(hipEventRecord(view_ready, s));
