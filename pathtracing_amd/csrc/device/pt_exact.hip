@@ -82,6 +82,9 @@ __global__ void k_packet_prep(DevScene S, ViewParams V, float4 *forms) {
 // mainOMP.cpp:60 has to be run (SearchNote); k_primary_shade does the rest of castRay from that record.
 // The kernel's arguments are one struct, read where they are needed through the kernel-argument pointer made opaque to
 // the compiler: what the walk does not need (the view, the output arrays) then does not sit in scalar registers while it runs.
+#ifndef PT_PRIMARY_STEAL
+#define PT_PRIMARY_STEAL 3u                       // other bands a wave of the search kernel tries after its own
+#endif
 struct PrimaryArgs { DevScene S; ViewParams V; FrameBuffers F; SubBuffers B; uint32_t nblocks; };
 typedef const PrimaryArgs __attribute__((address_space(4))) *PrimaryArgsU;
 PT_DEV PrimaryArgsU primary_args() {
@@ -107,18 +110,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_
     // from the counter of the image band of its group first (blockIdx % 8: the blocks of a group share an XCD and its L2, and
     // with it the band's part of the packet test's table), then from the other bands' until every band is drained
     uint32_t tries = 0;
+    const uint32_t max_tries = gridDim.x >= 64u ? 1u + PT_PRIMARY_STEAL : RC_HEAD_REGIONS;
     for (;;) {
         const PrimaryArgsU a0 = primary_args();
         const uint32_t nblocks = a0->nblocks, band = (nblocks + RC_HEAD_REGIONS - 1u) / RC_HEAD_REGIONS;
         uint32_t blk = 0;
-        while (tries < RC_HEAD_REGIONS) {
-            if (tries) {                             // has a wave of this group already found every band drained?
-                unsigned long long seen = 0;
-                if (lane == 0) seen = __hip_atomic_fetch_add((unsigned long long *)&a0->F.counters[RC_FLAGS + (blockIdx.x & (RC_HEAD_REGIONS - 1u)) * RC_HEAD_STRIDE], 2ull,
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__builtin_amdgcn_readfirstlane((uint32_t)seen) & 1u) { tries = RC_HEAD_REGIONS; break; }
-            }
-            const uint32_t h = (blockIdx.x + tries) & (RC_HEAD_REGIONS - 1u);
+        while (tries < max_tries) {
+            // its own band, then one other (which one depends on the block), then it leaves: see pt_persistent.h on the end of a launch
+            const uint32_t home = blockIdx.x & (RC_HEAD_REGIONS - 1u);
+            const uint32_t h = tries == 0 ? home : (home + 1u + ((blockIdx.x >> 3) + tries - 1u) % (RC_HEAD_REGIONS - 1u)) & (RC_HEAD_REGIONS - 1u);
             const uint32_t lo = h * band < nblocks ? h * band : nblocks, hi = lo + band < nblocks ? lo + band : nblocks;
             uint32_t at = 0;
             if (lane == 0 && lo < hi) at = (uint32_t)atomicAdd(&a0->F.counters[RC_HEADS + h * RC_HEAD_STRIDE], 1ull);
@@ -126,10 +126,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_
             if (lo < hi && at < hi - lo) { blk = lo + at; break; }
             tries++;
         }
-        if (tries == RC_HEAD_REGIONS) {
-            if (lane == 0) atomicOr((unsigned long long *)&a0->F.counters[RC_FLAGS + (blockIdx.x & (RC_HEAD_REGIONS - 1u)) * RC_HEAD_STRIDE], 1ull);
-            break;
-        }
+        if (tries == max_tries) break;
         int i = 0, j = 0, sub = 4;
         bool live;
         RayD ray;

@@ -352,12 +352,23 @@ struct ClosestPolicy {
     }
 };
 
+// PT_TRACE_CLOCKS (an instrumented build for tools/trace_exit.sh, never the product): when every wave of the closest-hit
+// launch began and ended, on the 100 MHz clock.
+#ifdef PT_TRACE_CLOCKS
+__device__ unsigned long long g_trace_clk[2][PT_TRACE_WAVES];
+#endif
 template <bool COUNT, class LS>
 __global__ void __launch_bounds__(64) k_trace_closest(DevScene S, FastBuffers Q, uint32_t slot_mask, int refill_min, uint32_t chunk) {
     extern __shared__ uint2 stack[];            // (slot_mask + 1) * 64 entries
+#ifdef PT_TRACE_CLOCKS
+    if ((threadIdx.x & 63) == 0) g_trace_clk[0][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     ClosestPolicy<COUNT, LS> P{S, Q, root_box(S), stack + (threadIdx.x & 63), slot_mask};
     P.work[0] = P.work[1] = 0;
     persistent_loop(P, Q.counts[0], Q.heads, chunk, refill_min);
+#ifdef PT_TRACE_CLOCKS
+    if ((threadIdx.x & 63) == 0) g_trace_clk[1][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (COUNT) {
         for (int k = 0; k < 2; k++) {
             uint32_t v = P.work[k];
@@ -862,6 +873,19 @@ int fast_gi(const DevScene &S, const ViewParams &V, const FrameBuffers &F, const
         else
             hipLaunchKernelGGL((k_trace_closest<false, LaneState>), dim3(tblocks), dim3(64), lds, s, S, Q, smask, tune.refill, chunk);
         FQ(hipEventRecord(events[4 * pass + 2], s));
+#ifdef PT_TRACE_CLOCKS
+        {   // instrumented build: when the waves of this launch began and ended, as percentiles after the first wave's start (us)
+            static std::vector<unsigned long long> c(2 * (size_t)PT_TRACE_WAVES);
+            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(c.data(), HIP_SYMBOL(g_trace_clk), c.size() * 8) == hipSuccess) {
+                std::vector<double> b(c.begin(), c.begin() + tblocks), e(c.begin() + PT_TRACE_WAVES, c.begin() + PT_TRACE_WAVES + tblocks);
+                std::sort(b.begin(), b.end()); std::sort(e.begin(), e.end());
+                const double t0 = b[0];
+                auto pc = [&](const std::vector<double> &v, double q) { return (v[(size_t)(q * (v.size() - 1))] - t0) / 100.0; };
+                fprintf(stderr, "trace_clk rays %zu waves %u begin p50 %.1f p99 %.1f max %.1f  end p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n", (size_t)(P * nb), tblocks,
+                        pc(b, .5), pc(b, .99), pc(b, 1), pc(e, .01), pc(e, .1), pc(e, .5), pc(e, .9), pc(e, .99), pc(e, 1));
+            }
+        }
+#endif
         if (V.model == PT_MODEL_MAIN) {
             hipLaunchKernelGGL(k_shade_gi<PT_MODEL_MAIN>, dim3(sblocks), dim3(PT_APPEND_BLOCK), (size_t)tune.shade_lds, s, S, Q);
             if (quads)

@@ -5,7 +5,8 @@
 // cache lines and memory channels).  A wave draws chunks of `chunk` items with
 // one atomicAdd per chunk from the region of its group (blockIdx % 8: blocks
 // of one group share an XCD and its L2) and moves on to the next region when
-// that one is drained, so the grid always empties every region.  Why:
+// that one is drained (see below for how far it goes), so the grid always empties
+// every region.  Why:
 //   * a single head word takes only ~90 atomics per microsecond chip-wide;
 //     at 64 items per chunk that is a floor of 2.9 ms for 16.7 M items;
 //   * small chunks keep the window of items in flight short -- the items are
@@ -32,21 +33,15 @@
 #define PT_HEAD_STRIDE 64u                    // words between region heads
 #define PT_HEAD_WORDS (PT_QUEUE_REGIONS * PT_HEAD_STRIDE)
 
-// The end of a launch: every wave has to find every region drained, and 8 192 waves each adding to each of the eight
-// head words queue up for 90 us per word.  The first wave of a group that has seen all eight drained therefore says so in a
-// word of its group, and the other waves of the group look there before they try another region: two or three updates
-// per wave at the end instead of eight.  The word only ever says what is true for good (heads only grow); a wave that
-// looks too early checks the regions itself, as before.
-__device__ __forceinline__ bool group_done(uint32_t *heads, uint32_t home) {
-    uint32_t v = 0;
-    // (an update that changes the word -- it counts the lookers in the bits above the flag -- so that it is not turned into a
-    // load that a cache may answer with an old value)
-    if ((threadIdx.x & 63) == 0) v = __hip_atomic_fetch_add(heads + home * PT_HEAD_STRIDE + PT_HEAD_STRIDE / 2, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return (__builtin_amdgcn_readfirstlane(v) & 1u) != 0u;
-}
-__device__ __forceinline__ void group_is_done(uint32_t *heads, uint32_t home) {
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(heads + home * PT_HEAD_STRIDE + PT_HEAD_STRIDE / 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// The end of a launch is a stampede: thousands of waves find their region drained within microseconds of one another, and
+// if each then tries every other region, every head word takes one update per wave of the launch, each queued behind a
+// thousand others at ~90 updates per microsecond.  A wave therefore tries PT_STEAL_TRIES other regions after its own (which
+// ones depends on the block, so that every region gets help from some of every other group) and then leaves; every region
+// is emptied by its own group in any case.  Same-box A/B, ms per 16-spp -rb view, 1 / 3 / 7 other regions: atrium 2.15 /
+// 2.13 / 2.14, car 0.97 / 0.98 / 1.03.  Launches of fewer than 64 blocks, where a region may have no wave of its own, try all.
+#ifndef PT_STEAL_TRIES
+#define PT_STEAL_TRIES 3u
+#endif
 
 template <class Policy>
 __device__ __forceinline__ void persistent_loop(Policy &P, uint32_t n_items, uint32_t *heads, uint32_t chunk, int refill_min) {
@@ -54,15 +49,16 @@ __device__ __forceinline__ void persistent_loop(Policy &P, uint32_t n_items, uin
     // region length: a multiple of 64 so that a wave's 64 consecutive items stay in one region
     const uint32_t region_len = (((n_items + PT_QUEUE_REGIONS - 1u) / PT_QUEUE_REGIONS) + 63u) & ~63u;
     const uint32_t home = blockIdx.x & (PT_QUEUE_REGIONS - 1u);
+    const uint32_t max_tries = gridDim.x >= 64u ? 1u + PT_STEAL_TRIES : PT_QUEUE_REGIONS;
     bool active = false, more = true;
     uint32_t chunk_next = 0, chunk_end = 0, tries = 0;
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         if (more && __popcll(idle) >= refill_min) {
             if (chunk_next == chunk_end) {
-                while (tries < PT_QUEUE_REGIONS) {
-                    if (tries && group_done(heads, home)) { tries = PT_QUEUE_REGIONS; break; }
-                    const uint32_t h = (home + tries) & (PT_QUEUE_REGIONS - 1u);
+                while (tries < max_tries) {
+                    // the region tried after the wave's own: own + 1 + (block / 8) % 7, the one after that the next, ...
+                    const uint32_t h = tries == 0 ? home : (home + 1u + ((blockIdx.x >> 3) + tries - 1u) % (PT_QUEUE_REGIONS - 1u)) & (PT_QUEUE_REGIONS - 1u);
                     const uint32_t lo = h * region_len < n_items ? h * region_len : n_items;
                     const uint32_t hi = lo + region_len < n_items ? lo + region_len : n_items;
                     uint32_t base = 0;
@@ -75,7 +71,7 @@ __device__ __forceinline__ void persistent_loop(Policy &P, uint32_t n_items, uin
                     }
                     tries++;
                 }
-                if (tries == PT_QUEUE_REGIONS) { more = false; group_is_done(heads, home); }
+                if (tries == max_tries) more = false;
             }
             const uint32_t want = (uint32_t)__popcll(idle), have = chunk_end - chunk_next;
             const uint32_t take = want < have ? want : have, base = chunk_next;

@@ -97,7 +97,4 @@ enum { RC_PRIMARY = 0, RC_SHADOW = 1, RC_MIRROR = 2, RC_GI = 3, RC_RETRACE = 4, 
 // image, each in a cache line of its own behind the counters above (updates of ONE word run at some 90 per microsecond
 // on the whole chip: at 37 888 packets per view a single counter was a quarter of the kernel's time on small scenes).
 // Words 1 .. 5 of a band's line: the rays per class counted by the blocks of that group (blockIdx % 8).
-// RC_FLAGS: one word per group in a line of its own, set by the first wave of the group that has found every band drained and
-// looked at by the others before they try another band (pt_persistent.h says why).
-enum { RC_HEADS = 32, RC_HEAD_STRIDE = 16, RC_HEAD_REGIONS = 8, RC_FLAGS = RC_HEADS + RC_HEAD_REGIONS * RC_HEAD_STRIDE,
-       RC_WORDS = RC_FLAGS + RC_HEAD_REGIONS * RC_HEAD_STRIDE };
+enum { RC_HEADS = 32, RC_HEAD_STRIDE = 16, RC_HEAD_REGIONS = 8, RC_WORDS = RC_HEADS + RC_HEAD_REGIONS * RC_HEAD_STRIDE };
