@@ -8,10 +8,6 @@
 #include "pt_frame.h"
 #include "pt_packet.h"
 
-// Work blocks a resident wave draws per update of a view's work counter: updates of one word run at some 90 per
-// microsecond on the whole chip, and a -rb view is 38 000 blocks.
-#define PT_WORK_DRAW 4u
-
 // 8x8 pixel tiles: one wave = one tile, so that the rays of a wave stay close.
 PT_DEV bool tile_pixel(int linear, int size, int &i, int &j) {
     int tiles_x = (size + 7) >> 3;
@@ -30,6 +26,24 @@ PT_DEV uint32_t wave_sum(uint32_t v) {
 // The word a block adds its count of ray class k to: one set of class words per group of blocks (see RC_HEADS), summed by the host.
 PT_DEV unsigned long long *count_word(unsigned long long *counters, int k) {
     return counters + RC_HEADS + (blockIdx.x & (RC_HEAD_REGIONS - 1u)) * RC_HEAD_STRIDE + 1u + (unsigned)k;
+}
+// The next work block of a persistent kernel whose nblocks blocks are handed out from the eight per-band counters in word
+// `word` of the bands' lines (RC_HEADS): from the band of the block's group first, then from up to `steal` other bands
+// (which ones depends on the block; a launch of fewer than 64 blocks tries all).  false: nothing left for this wave.
+// Every lane of the wave must call it; `tries` is the wave's progress through its bands, 0 at the start.
+PT_DEV bool draw_block(unsigned long long *counters, uint32_t word, uint32_t nblocks, uint32_t steal, uint32_t &tries, uint32_t &blk) {
+    const uint32_t band = (nblocks + RC_HEAD_REGIONS - 1u) / RC_HEAD_REGIONS, home = blockIdx.x & (RC_HEAD_REGIONS - 1u);
+    const uint32_t max_tries = gridDim.x >= 64u ? 1u + steal : RC_HEAD_REGIONS;
+    while (tries < max_tries) {
+        const uint32_t h = tries == 0 ? home : (home + 1u + ((blockIdx.x >> 3) + tries - 1u) % (RC_HEAD_REGIONS - 1u)) & (RC_HEAD_REGIONS - 1u);
+        const uint32_t lo = h * band < nblocks ? h * band : nblocks, hi = lo + band < nblocks ? lo + band : nblocks;
+        uint32_t at = 0;
+        if ((threadIdx.x & 63) == 0 && lo < hi) at = (uint32_t)atomicAdd(&counters[RC_HEADS + h * RC_HEAD_STRIDE + word], 1ull);
+        at = __builtin_amdgcn_readfirstlane(at);
+        if (lo < hi && at < hi - lo) { blk = lo + at; return true; }
+        tries++;
+    }
+    return false;
 }
 PT_DEV void flush_counts(const RayCounts &rc, unsigned long long *counters) {
 #pragma unroll
@@ -110,23 +124,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PKT_
     // from the counter of the image band of its group first (blockIdx % 8: the blocks of a group share an XCD and its L2, and
     // with it the band's part of the packet test's table), then from the other bands' until every band is drained
     uint32_t tries = 0;
-    const uint32_t max_tries = gridDim.x >= 64u ? 1u + PT_PRIMARY_STEAL : RC_HEAD_REGIONS;
     for (;;) {
         const PrimaryArgsU a0 = primary_args();
-        const uint32_t nblocks = a0->nblocks, band = (nblocks + RC_HEAD_REGIONS - 1u) / RC_HEAD_REGIONS;
         uint32_t blk = 0;
-        while (tries < max_tries) {
-            // its own band, then one other (which one depends on the block), then it leaves: see pt_persistent.h on the end of a launch
-            const uint32_t home = blockIdx.x & (RC_HEAD_REGIONS - 1u);
-            const uint32_t h = tries == 0 ? home : (home + 1u + ((blockIdx.x >> 3) + tries - 1u) % (RC_HEAD_REGIONS - 1u)) & (RC_HEAD_REGIONS - 1u);
-            const uint32_t lo = h * band < nblocks ? h * band : nblocks, hi = lo + band < nblocks ? lo + band : nblocks;
-            uint32_t at = 0;
-            if (lane == 0 && lo < hi) at = (uint32_t)atomicAdd(&a0->F.counters[RC_HEADS + h * RC_HEAD_STRIDE], 1ull);
-            at = __builtin_amdgcn_readfirstlane(at);
-            if (lo < hi && at < hi - lo) { blk = lo + at; break; }
-            tries++;
-        }
-        if (tries == max_tries) break;
+        if (!draw_block((unsigned long long *)a0->F.counters, 0u, a0->nblocks, PT_PRIMARY_STEAL, tries, blk)) break;
         int i = 0, j = 0, sub = 4;
         bool live;
         RayD ray;
@@ -222,13 +223,8 @@ __global__ void __launch_bounds__(64) k_primary_shade(DevScene S, ViewParams V, 
 #pragma unroll
     for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t blk = 0, blk_end = 0;; blk++) {
-        if (blk == blk_end) {                        // PT_WORK_DRAW work blocks per update of the counter
-            if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_SHADE], (unsigned long long)PT_WORK_DRAW);
-            blk = __builtin_amdgcn_readfirstlane(blk);
-            if (blk >= nblocks) break;
-            blk_end = blk + PT_WORK_DRAW < nblocks ? blk + PT_WORK_DRAW : nblocks;
-        }
+    for (uint32_t blk = 0, tries = 0;;) {
+        if (!draw_block(F.counters, 8u, nblocks, PT_PRIMARY_STEAL, tries, blk)) break;      // (word 8 of the bands' lines)
         uint32_t lin;
         int sub = 4;
         bool live = true;
@@ -303,13 +299,8 @@ __global__ void __launch_bounds__(64) k_mirror_exact(DevScene S, ViewParams V, F
 #pragma unroll
     for (int k = 0; k < RC_N; k++) rc.n[k] = 0;
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t blk = 0, blk_end = 0;; blk++) {
-        if (blk == blk_end) {                        // PT_WORK_DRAW work blocks per update of the counter
-            if (lane == 0) blk = (uint32_t)atomicAdd(&F.counters[RC_WORK_MIRROR], (unsigned long long)PT_WORK_DRAW);
-            blk = __builtin_amdgcn_readfirstlane(blk);
-            if (blk >= nblocks) break;
-            blk_end = blk + PT_WORK_DRAW < nblocks ? blk + PT_WORK_DRAW : nblocks;
-        }
+    for (uint32_t blk = 0, tries = 0;;) {
+        if (!draw_block(F.counters, 9u, nblocks, PT_PRIMARY_STEAL, tries, blk)) break;      // (word 9 of the bands' lines)
         uint32_t lin;
         int sub = 0;
         bool live = true;
