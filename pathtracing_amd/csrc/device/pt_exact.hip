@@ -27,6 +27,9 @@ PT_DEV uint32_t wave_sum(uint32_t v) {
 PT_DEV unsigned long long *count_word(unsigned long long *counters, int k) {
     return counters + RC_HEADS + (blockIdx.x & (RC_HEAD_REGIONS - 1u)) * RC_HEAD_STRIDE + 1u + (unsigned)k;
 }
+#ifndef PT_BAND_INTERLEAVE
+#define PT_BAND_INTERLEAVE 32u                   // 0: a band is a contiguous eighth of the blocks; n: runs of n blocks dealt to the bands in turn
+#endif
 // The next work block of a persistent kernel whose nblocks blocks are handed out from the eight per-band counters in word
 // `word` of the bands' lines (RC_HEADS): from the band of the block's group first, then from up to `steal` other bands
 // (which ones depends on the block; a launch of fewer than 64 blocks tries all).  false: nothing left for this wave.
@@ -36,13 +39,28 @@ PT_DEV bool draw_block(unsigned long long *counters, uint32_t word, uint32_t nbl
     const uint32_t max_tries = gridDim.x >= 64u ? 1u + steal : RC_HEAD_REGIONS;
     while (tries < max_tries) {
         const uint32_t h = tries == 0 ? home : (home + 1u + ((blockIdx.x >> 3) + tries - 1u) % (RC_HEAD_REGIONS - 1u)) & (RC_HEAD_REGIONS - 1u);
+#if PT_BAND_INTERLEAVE
+        // band h: the runs of PT_BAND_INTERLEAVE consecutive blocks number h, h + 8, h + 16, ...
+        const uint32_t runs = (nblocks + PT_BAND_INTERLEAVE - 1u) / PT_BAND_INTERLEAVE, mine = runs > h ? (runs - h + RC_HEAD_REGIONS - 1u) / RC_HEAD_REGIONS : 0u;
+        const uint32_t lo = 0, hi = mine * PT_BAND_INTERLEAVE;
+#else
         const uint32_t lo = h * band < nblocks ? h * band : nblocks, hi = lo + band < nblocks ? lo + band : nblocks;
+#endif
         uint32_t at = 0;
         if ((threadIdx.x & 63) == 0 && lo < hi) at = (uint32_t)atomicAdd(&counters[RC_HEADS + h * RC_HEAD_STRIDE + word], 1ull);
         at = __builtin_amdgcn_readfirstlane(at);
-        if (lo < hi && at < hi - lo) { blk = lo + at; return true; }
+        if (lo < hi && at < hi - lo) {
+#if PT_BAND_INTERLEAVE
+            blk = ((at / PT_BAND_INTERLEAVE) * RC_HEAD_REGIONS + h) * PT_BAND_INTERLEAVE + at % PT_BAND_INTERLEAVE;
+            if (blk >= nblocks) continue;                // the last run is short: draw again
+#else
+            blk = lo + at;
+#endif
+            return true;
+        }
         tries++;
     }
+    (void)band;
     return false;
 }
 PT_DEV void flush_counts(const RayCounts &rc, unsigned long long *counters) {
