@@ -305,6 +305,8 @@ def rm_rb16_leg(ds, cams, size, rank, world, dev, xdev, dist, backend):
             "mrays_per_s": round(rays / dt / 1e6, 1),
             # device time per view of the two passes that make up a view (several views are in flight per GPU, so these overlap in wall time)
             "primary_ms": round(tot["ms_primary"] / n, 4), "closest_ms": round(tot["ms_gi_trace"] / n, 4),
+            "stage_ms_note": "event-to-event time on the view's stream with several views in flight per GPU: each includes waiting for and running "
+                             "beside other views' kernels, so the two add up to more than ms_per_view; one view at a time: bench.py --rb --spp 16",
             "frames_on_rank0": got[0], "backend": backend if world > 1 else None}
 
 
